@@ -1,0 +1,135 @@
+/*
+ * rawformer_hip.h -- C ABI of the MI355X (gfx950) RawFormer inference path.
+ *
+ * This is the drop-in boundary.  The reference is pure
+ * Python/PyTorch with no FFI of its own; what a maintainer would bind is the
+ * call `pred = model(inp)` in test.py:116 (RawFomer_WFB_FFAB/test.py:78), i.e.
+ * `RawFormer.forward` (RawFomer_WFB_FFAB/model.py:473-508 ==
+ * FrequencyawareLumaChromaAttentionRAWFormer.py:330-370), plus the operators it
+ * is made of.  Every entry point below names the reference function it
+ * replaces.  INTEGRATION.md shows the ctypes stub.
+ *
+ * Conventions
+ *   - plain C types only; every pointer is a DEVICE pointer to float32 unless
+ *     the comment says host;
+ *   - tensors are NCHW, contiguous;
+ *   - `stream` is a hipStream_t passed as void* (NULL = default stream); all
+ *     calls are asynchronous on it and allocate nothing;
+ *   - return value 0 = ok, negative = error (RF_E_*); rf_last_error() gives the
+ *     message of the calling thread's last failure;
+ *   - a handle is re-entrant across handles, not thread-safe on one handle.
+ */
+#ifndef RAWFORMER_HIP_H
+#define RAWFORMER_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define RF_OK 0
+#define RF_E_INVALID (-22)   /* bad argument / shape          */
+#define RF_E_NOMEM (-12)     /* workspace too small           */
+#define RF_E_MISSING (-2)    /* a required parameter not set  */
+#define RF_E_DEVICE (-5)     /* HIP runtime error             */
+
+#define RF_VARIANT_FLCA 0    /* FrequencyawareLumaChromaAttentionRAWFormer.py:257-278 branch */
+#define RF_VARIANT_PLAIN 1   /* conv branch: RawFomer_WFB_FFAB/model.py:393-412, model.py:94-108 */
+
+typedef struct rf_handle rf_handle;
+
+typedef struct rf_config {
+    int32_t dim;              /* 32 / 48 / 64 (any multiple of 8)                     */
+    int32_t heads[4];         /* per U-Net level, reference default {8,8,8,8}         */
+    int32_t inp_channels;     /* 1 (Bayer mosaic)                                     */
+    int32_t out_channels;     /* 3                                                    */
+    int32_t ffn_expansion;    /* 2                                                    */
+    int32_t variant;          /* RF_VARIANT_*                                         */
+    int32_t branch_lrelu;     /* plain variant: LeakyReLU on the conv branch (WFB) or not (model.py) */
+    int32_t clamp_io;         /* clamp input and output to [0,1]: RawFomer_WFB_FFAB/model.py:475,508 */
+} rf_config;
+
+const char* rf_last_error(void);
+int rf_version(void);
+
+/* ---- whole model: RawFormer.__init__/load_state_dict/forward ------------------------------ */
+int rf_create(const rf_config* cfg, rf_handle** out);
+void rf_destroy(rf_handle* h);
+/* Parameter registry: names are the reference's state_dict keys
+ * (FrequencyawareLumaChromaAttentionRAWFormer.py:297-328).  Pointers are borrowed. */
+int rf_param_count(const rf_handle* h);
+int rf_param_info(const rf_handle* h, int index, const char** name, int64_t shape[4], int* ndim);
+int rf_set_param(rf_handle* h, const char* name, const float* dev_ptr, const int64_t* shape, int ndim);
+/* Repack the registered weights into MFMA operand order inside caller memory.  Call again
+ * whenever a parameter tensor changed. */
+int rf_packed_bytes(const rf_handle* h, size_t* bytes);
+int rf_pack_params(rf_handle* h, void* packed_dev, size_t bytes, void* stream);
+/* H, W are the PACKED sizes (mosaic is 2H x 2W); both must be multiples of 8. */
+int rf_workspace_bytes(const rf_handle* h, int B, int H, int W, size_t* bytes);
+/* in: mosaic [B, inp_channels, 2H, 2W] (packed_input = 0) or packed [B, 4*inp_channels, H, W];
+ * out: [B, out_channels, 2H, 2W].  Replaces RawFormer.forward (test.py:116). */
+int rf_forward(rf_handle* h, const float* in, float* out, void* workspace, size_t workspace_bytes,
+               int B, int H, int W, int packed_input, void* stream);
+
+/* ---- operators (parity-test surface; the same kernels the forward uses) ------------------- */
+/* downshuffle(var, 2): RawFomer_WFB_FFAB/model.py:287-298.  [B,C,2h,2w] -> [B,4C,h,w] */
+int rf_pixel_unshuffle2(const float* in, float* out, int B, int C, int h, int w, void* stream);
+/* nn.PixelShuffle(2): RawFomer_WFB_FFAB/model.py:471,507.    [B,4C,h,w] -> [B,C,2h,2w] */
+int rf_pixel_shuffle2(const float* in, float* out, int B, int C, int h, int w, void* stream);
+/* dwt_init / DWT: RawFomer_WFB_FFAB/blocks.py:102-115.       [B,C,2h,2w] -> [4B,C,h,w] (LL,HL,LH,HH) */
+int rf_dwt_haar(const float* in, float* out, int B, int C, int h, int w, void* stream);
+/* iwt_init / IWT: RawFomer_WFB_FFAB/blocks.py:119-136.       [4B,C,h,w] -> [B,C,2h,2w] */
+int rf_idwt_haar(const float* in, float* out, int B, int C, int h, int w, void* stream);
+/* CustomDWT: README.md:92-117.  k16 = HOST pointer to the 4x4 kernel, row-major; norm!=0 halves it.
+ * [B,C,2h,2w] -> [B,4C,h,w], sub-band-major channels. */
+int rf_dwt_custom(const float* in, float* out, const float* k16, int norm, int B, int C, int h, int w, void* stream);
+/* CustomIDWT: README.md:120-144.  [B,4C,h,w] -> [B,C,2h,2w] */
+int rf_idwt_custom(const float* in, float* out, const float* k16, int norm, int B, int C, int h, int w, void* stream);
+/* HaarDWT: FrequencyawareLumaChromaAttentionRAWFormer.py:39-73 (odd sizes reflect-padded).
+ * [B,C,hin,win] -> out[4][B,C,ceil(hin/2),ceil(win/2)] in the order LL, LH, HL, HH. */
+int rf_haar_dwt(const float* in, float* out, int B, int C, int hin, int win, void* stream);
+/* LayerNorm over channels: FrequencyawareLumaChromaAttentionRAWFormer.py:180-187;
+ * bias == NULL selects BiasFree_LayerNorm (RawFomer_WFB_FFAB/model.py:89-103). */
+int rf_layernorm2d(const float* in, float* out, const float* weight, const float* bias, float eps,
+                   int B, int C, int h, int w, void* stream);
+/* nn.Conv2d(Cin, Cout, 1) with raw [Cout,Cin] weights; scratch holds the repacked weights
+ * (rf_conv1x1_scratch_bytes).  Optional fused LayerNorm prologue (ln_w != NULL), residual add
+ * (res != NULL) and a second input (in2, C2 channels, concatenated after the first). */
+int rf_conv1x1_scratch_bytes(int Cin_total, int Cout, size_t* bytes);
+int rf_conv1x1(const float* in, const float* in2, float* out, const float* weight, const float* bias,
+               const float* ln_w, const float* ln_b, const float* res, void* scratch,
+               int B, int C1, int C2, int Cout, int h, int w, void* stream);
+/* nn.Conv2d(C, C, 3, padding=1, groups=C) (+bias), optional exact GELU: conv_ffn middle
+ * (RawFomer_WFB_FFAB/model.py:326-334). */
+int rf_dwconv3x3(const float* in, float* out, const float* weight, const float* bias, int gelu,
+                 int B, int C, int h, int w, void* stream);
+/* nn.Conv2d(Cin, Cout, 3, padding=1) with raw [Cout,Cin,3,3] weights.
+ * act: 0 none, 1 LeakyReLU(0.2).  store: 0 plain, 1 pixel-unshuffle (Downsample,
+ * RawFomer_WFB_FFAB/model.py:300-307), 2 pixel-shuffle (conv_out + PixelShuffle, :505-507). */
+int rf_conv3x3_scratch_bytes(int Cin, int Cout, size_t* bytes);
+int rf_conv3x3(const float* in, float* out, const float* weight, const float* bias, void* scratch,
+               int act, int store, int B, int Cin, int Cout, int h, int w, void* stream);
+/* nn.ConvTranspose2d(Cin, Cout, 2, stride=2) with raw [Cin,Cout,2,2] weights
+ * (RawFomer_WFB_FFAB/model.py:461).  [B,Cin,h,w] -> [B,Cout,2h,2w] */
+int rf_convT2x2_scratch_bytes(int Cin, int Cout, size_t* bytes);
+int rf_convT2x2(const float* in, float* out, const float* weight, const float* bias, void* scratch,
+                int B, int Cin, int Cout, int h, int w, void* stream);
+/* Attention.forward: FrequencyawareLumaChromaAttentionRAWFormer.py:212-235.
+ * Takes the 6 raw parameter tensors; scratch from rf_chan_attn_scratch_bytes. */
+int rf_chan_attn_scratch_bytes(int B, int C, int heads, int h, int w, size_t* bytes);
+int rf_chan_attn(const float* in, float* out, const float* qkv_w, const float* qkv_b,
+                 const float* dw_w, const float* dw_b, const float* temperature,
+                 const float* proj_w, const float* proj_b, void* scratch,
+                 int B, int C, int heads, int h, int w, void* stream);
+/* BayerLumaChroma + HaarDWT + bilinear resize = the guidance planes of FLCA
+ * (FrequencyawareLumaChromaAttentionRAWFormer.py:79-97,138-149).
+ * packed [B,4,H,W] -> guide [B,4,hf,wf] = (y_low, y_high, cr, cb); scratch >= rf_guidance_scratch_bytes. */
+int rf_guidance_scratch_bytes(int B, int H, int W, size_t* bytes);
+int rf_flca_guidance(const float* packed, float* guide, void* scratch, int B, int H, int W, int hf, int wf, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RAWFORMER_HIP_H */
