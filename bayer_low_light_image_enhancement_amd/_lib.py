@@ -1,0 +1,86 @@
+"""ctypes binding of ``csrc/librawformer_hip.so`` (the C ABI in ``include/rawformer_hip.h``).
+
+There is no fallback: if the library is missing or a call fails, a ``RuntimeError`` is raised
+(the reference's own error convention is Python exceptions).
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "csrc", "librawformer_hip.so")
+
+RF_VARIANT_FLCA = 0
+RF_VARIANT_PLAIN = 1
+
+
+class RfConfig(C.Structure):
+    _fields_ = [("dim", C.c_int32), ("heads", C.c_int32 * 4), ("inp_channels", C.c_int32),
+                ("out_channels", C.c_int32), ("ffn_expansion", C.c_int32), ("variant", C.c_int32),
+                ("branch_lrelu", C.c_int32), ("clamp_io", C.c_int32)]
+
+
+_vp, _i, _f, _sz = C.c_void_p, C.c_int, C.c_float, C.c_size_t
+_psz = C.POINTER(C.c_size_t)
+
+# name -> (restype, argtypes); mirrors include/rawformer_hip.h one to one
+SIGNATURES = {
+    "rf_last_error": (C.c_char_p, []),
+    "rf_version": (_i, []),
+    "rf_profile_begin": (_i, []),
+    "rf_profile_end": (_i, [C.c_char_p, _sz]),
+    "rf_create": (_i, [C.POINTER(RfConfig), C.POINTER(_vp)]),
+    "rf_destroy": (None, [_vp]),
+    "rf_param_count": (_i, [_vp]),
+    "rf_param_info": (_i, [_vp, _i, C.POINTER(C.c_char_p), C.POINTER(C.c_int64 * 4), C.POINTER(_i)]),
+    "rf_set_param": (_i, [_vp, C.c_char_p, _vp, C.POINTER(C.c_int64), _i]),
+    "rf_packed_bytes": (_i, [_vp, _psz]),
+    "rf_pack_params": (_i, [_vp, _vp, _sz, _vp]),
+    "rf_workspace_bytes": (_i, [_vp, _i, _i, _i, _psz]),
+    "rf_forward": (_i, [_vp, _vp, _vp, _vp, _sz, _i, _i, _i, _i, _vp]),
+    "rf_pixel_unshuffle2": (_i, [_vp, _vp, _i, _i, _i, _i, _vp]),
+    "rf_pixel_shuffle2": (_i, [_vp, _vp, _i, _i, _i, _i, _vp]),
+    "rf_dwt_haar": (_i, [_vp, _vp, _i, _i, _i, _i, _vp]),
+    "rf_idwt_haar": (_i, [_vp, _vp, _i, _i, _i, _i, _vp]),
+    "rf_dwt_custom": (_i, [_vp, _vp, C.POINTER(C.c_float), _i, _i, _i, _i, _i, _vp]),
+    "rf_idwt_custom": (_i, [_vp, _vp, C.POINTER(C.c_float), _i, _i, _i, _i, _i, _vp]),
+    "rf_haar_dwt": (_i, [_vp, _vp, _i, _i, _i, _i, _vp]),
+    "rf_layernorm2d": (_i, [_vp, _vp, _vp, _vp, _f, _i, _i, _i, _i, _vp]),
+    "rf_conv1x1_scratch_bytes": (_i, [_i, _i, _psz]),
+    "rf_conv1x1": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
+    "rf_dwconv3x3": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
+    "rf_conv3x3_scratch_bytes": (_i, [_i, _i, _psz]),
+    "rf_conv3x3": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp]),
+    "rf_convT2x2_scratch_bytes": (_i, [_i, _i, _psz]),
+    "rf_convT2x2": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
+    "rf_chan_attn_scratch_bytes": (_i, [_i, _i, _i, _i, _i, _psz]),
+    "rf_chan_attn": (_i, [_vp] * 10 + [_i] * 5 + [_vp]),
+    "rf_guidance_scratch_bytes": (_i, [_i, _i, _i, _psz]),
+    "rf_flca_guidance": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
+}
+
+_lib = None
+
+
+def load() -> C.CDLL:
+    """Load the HIP library (once).  Raises if it has not been built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(
+                f"{LIB_PATH} not found: build it with `python -m bayer_low_light_image_enhancement_amd.build` "
+                "(hipcc, gfx950).  There is no CPU fallback for the RawFormer HIP path.")
+        lib = C.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(lib, name)   # AttributeError here = header and library out of sync
+            fn.restype = res
+            fn.argtypes = args
+        _lib = lib
+    return _lib
+
+
+def check(rc: int, what: str) -> None:
+    if rc != 0:
+        msg = load().rf_last_error()
+        raise RuntimeError(f"{what} failed ({rc}): {msg.decode() if msg else 'unknown error'}")

@@ -1,0 +1,299 @@
+// C-ABI operator entry points (include/rawformer_hip.h) and error plumbing.
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <string>
+#include <vector>
+#include "rf_common.h"
+
+namespace rf {
+
+static thread_local char g_err[512] = "";
+
+void set_error(const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+
+int check_hip(hipError_t e, const char* what) {
+    if (e == hipSuccess) return RF_OK;
+    set_error("%s: %s", what, hipGetErrorString(e));
+    return RF_E_DEVICE;
+}
+
+int check_launch(const char* what) { return check_hip(hipGetLastError(), what); }
+
+// ---- per-launch event profiler (single-threaded diagnostic; off by default)
+struct ProfRec {
+    std::string key;
+    double flops, bytes;
+    hipEvent_t e0, e1;
+};
+static bool g_prof_on = false;
+static std::vector<ProfRec> g_prof;
+
+ProfScope::ProfScope(hipStream_t st, const char* key, double flops, double bytes) : st_(st), rec_(-1) {
+    if (!g_prof_on) return;
+    ProfRec r;
+    r.key = key;
+    r.flops = flops;
+    r.bytes = bytes;
+    if (hipEventCreate(&r.e0) != hipSuccess || hipEventCreate(&r.e1) != hipSuccess) return;
+    (void)hipEventRecord(r.e0, st);
+    rec_ = (int)g_prof.size();
+    g_prof.push_back(r);
+}
+
+ProfScope::~ProfScope() {
+    if (rec_ >= 0) (void)hipEventRecord(g_prof[rec_].e1, st_);
+}
+
+static const float kHaarInit[16] = {   // dwt_init / iwt_init, taps t = 2*row + col, bands LL,HL,LH,HH
+    0.5f, 0.5f, 0.5f, 0.5f, -0.5f, 0.5f, -0.5f, 0.5f, -0.5f, -0.5f, 0.5f, 0.5f, 0.5f, -0.5f, -0.5f, 0.5f};
+static const float kHaarOrtho[16] = {  // HaarDWT, bands LL,LH,HL,HH
+    0.5f, 0.5f, 0.5f, 0.5f, 0.5f, -0.5f, 0.5f, -0.5f, 0.5f, 0.5f, -0.5f, -0.5f, 0.5f, -0.5f, -0.5f, 0.5f};
+
+}  // namespace rf
+
+using namespace rf;
+
+#define RF_TRY(expr)            \
+    do {                        \
+        const int rc_ = (expr); \
+        if (rc_) return rc_;    \
+    } while (0)
+
+extern "C" {
+
+const char* rf_last_error(void) { return g_err; }
+int rf_version(void) { return 1; }
+
+int rf_profile_begin(void) {
+    for (auto& r : g_prof) { (void)hipEventDestroy(r.e0); (void)hipEventDestroy(r.e1); }
+    g_prof.clear();
+    g_prof_on = true;
+    return RF_OK;
+}
+
+int rf_profile_end(char* json, size_t len) {
+    g_prof_on = false;
+    struct Agg { long n = 0; double ms = 0, flops = 0, bytes = 0; };
+    std::map<std::string, Agg> agg;
+    int rc = RF_OK;
+    for (auto& r : g_prof) {
+        float ms = 0.f;
+        if (hipEventSynchronize(r.e1) != hipSuccess || hipEventElapsedTime(&ms, r.e0, r.e1) != hipSuccess) rc = RF_E_DEVICE;
+        Agg& a = agg[r.key];
+        a.n += 1; a.ms += ms; a.flops += r.flops; a.bytes += r.bytes;
+        (void)hipEventDestroy(r.e0);
+        (void)hipEventDestroy(r.e1);
+    }
+    g_prof.clear();
+    if (rc) { set_error("rf_profile_end: event timing failed"); return rc; }
+    std::string out = "[";
+    bool first = true;
+    for (auto& kv : agg) {
+        char buf[512];
+        snprintf(buf, sizeof(buf), "%s{\"kernel\": \"%s\", \"launches\": %ld, \"ms\": %.6f, \"flops\": %.6e, \"bytes\": %.6e}",
+                 first ? "" : ", ", kv.first.c_str(), kv.second.n, kv.second.ms, kv.second.flops, kv.second.bytes);
+        out += buf;
+        first = false;
+    }
+    out += "]";
+    RF_CHECK_ARG(json && out.size() + 1 <= len, "rf_profile_end: buffer of %zu bytes too small (need %zu)", len, out.size() + 1);
+    memcpy(json, out.c_str(), out.size() + 1);
+    return RF_OK;
+}
+
+int rf_pixel_unshuffle2(const float* in, float* out, int B, int C, int h, int w, void* stream) {
+    RF_CHECK_ARG(in && out && B > 0 && C > 0 && h > 0 && w > 0, "pixel_unshuffle2: bad arguments");
+    return launch_pixel_unshuffle2(in, out, B, C, h, w, (hipStream_t)stream);
+}
+
+int rf_pixel_shuffle2(const float* in, float* out, int B, int C, int h, int w, void* stream) {
+    RF_CHECK_ARG(in && out && B > 0 && C > 0 && h > 0 && w > 0, "pixel_shuffle2: bad arguments");
+    return launch_pixel_shuffle2(in, out, B, C, h, w, (hipStream_t)stream);
+}
+
+int rf_dwt_haar(const float* in, float* out, int B, int C, int h, int w, void* stream) {
+    RF_CHECK_ARG(in && out && B > 0 && C > 0 && h > 0 && w > 0, "dwt_haar: bad arguments");
+    return launch_dwt2x2(in, out, kHaarInit, 0, 1, B, C, h, w, 2 * h, 2 * w, (hipStream_t)stream);
+}
+
+int rf_idwt_haar(const float* in, float* out, int B, int C, int h, int w, void* stream) {
+    RF_CHECK_ARG(in && out && B > 0 && C > 0 && h > 0 && w > 0, "idwt_haar: bad arguments");
+    return launch_idwt2x2(in, out, kHaarInit, 0, 1, B, C, h, w, (hipStream_t)stream);
+}
+
+static void scaled_kernel(const float* k16, int norm, float out[16]) {
+    for (int i = 0; i < 16; ++i) out[i] = norm ? k16[i] / 2.0f : k16[i];
+}
+
+int rf_dwt_custom(const float* in, float* out, const float* k16, int norm, int B, int C, int h, int w, void* stream) {
+    RF_CHECK_ARG(in && out && k16 && B > 0 && C > 0 && h > 0 && w > 0, "dwt_custom: bad arguments");
+    float k[16];
+    scaled_kernel(k16, norm, k);
+    return launch_dwt2x2(in, out, k, 1, 0, B, C, h, w, 2 * h, 2 * w, (hipStream_t)stream);
+}
+
+int rf_idwt_custom(const float* in, float* out, const float* k16, int norm, int B, int C, int h, int w, void* stream) {
+    RF_CHECK_ARG(in && out && k16 && B > 0 && C > 0 && h > 0 && w > 0, "idwt_custom: bad arguments");
+    float k[16];
+    scaled_kernel(k16, norm, k);
+    return launch_idwt2x2(in, out, k, 1, 0, B, C, h, w, (hipStream_t)stream);
+}
+
+int rf_haar_dwt(const float* in, float* out, int B, int C, int hin, int win, void* stream) {
+    RF_CHECK_ARG(in && out && B > 0 && C > 0 && hin > 1 && win > 1, "haar_dwt: bad arguments");
+    return launch_dwt2x2(in, out, kHaarOrtho, 0, 0, B, C, (hin + 1) / 2, (win + 1) / 2, hin, win, (hipStream_t)stream);
+}
+
+int rf_layernorm2d(const float* in, float* out, const float* weight, const float* bias, float eps,
+                   int B, int C, int h, int w, void* stream) {
+    RF_CHECK_ARG(in && out && weight && B > 0 && C > 0 && h > 0 && w > 0, "layernorm2d: bad arguments");
+    return launch_layernorm2d(in, out, weight, bias, eps, B, C, h * w, (hipStream_t)stream);
+}
+
+int rf_conv1x1_scratch_bytes(int Cin_total, int Cout, size_t* bytes) {
+    RF_CHECK_ARG(bytes && Cin_total > 0 && Cout > 0, "conv1x1_scratch_bytes: bad arguments");
+    *bytes = packed1x1_floats(Cin_total, Cout) * sizeof(float);
+    return RF_OK;
+}
+
+int rf_conv1x1(const float* in, const float* in2, float* out, const float* weight, const float* bias,
+               const float* ln_w, const float* ln_b, const float* res, void* scratch,
+               int B, int C1, int C2, int Cout, int h, int w, void* stream) {
+    RF_CHECK_ARG(in && out && weight && scratch && aligned16(scratch), "conv1x1: bad arguments");
+    hipStream_t st = (hipStream_t)stream;
+    const int K = C1 + C2;
+    RF_TRY(pack_1x1(weight, (float*)scratch, Cout, K, K, 1, st));
+    Conv1x1Args a{};
+    a.x1 = in; a.C1 = C1; a.x1_bstride = (int64_t)C1 * h * w;
+    a.x2 = C2 ? in2 : nullptr; a.C2 = C2; a.x2_bstride = (int64_t)C2 * h * w;
+    a.wp = (const float*)scratch; a.bias = bias; a.ln_w = ln_w; a.ln_b = ln_b; a.ln_eps = 1e-5f;
+    a.res = res; a.res_bstride = (int64_t)Cout * h * w;
+    a.out = out; a.out_bstride = (int64_t)Cout * h * w; a.Cout = Cout; a.B = B; a.P = h * w; a.w = w;
+    return launch_conv1x1(a, st);
+}
+
+int rf_dwconv3x3(const float* in, float* out, const float* weight, const float* bias, int gelu,
+                 int B, int C, int h, int w, void* stream) {
+    RF_CHECK_ARG(in && out && weight && B > 0 && C > 0 && h > 0 && w > 0, "dwconv3x3: bad arguments");
+    DwConvArgs a{};
+    a.x = in; a.x_bstride = (int64_t)C * h * w; a.out = out; a.out_bstride = (int64_t)C * h * w;
+    a.w = weight; a.bias = bias; a.B = B; a.C = C; a.h = h; a.w_ = w; a.gelu = gelu;
+    return launch_dwconv3x3(a, (hipStream_t)stream);
+}
+
+int rf_conv3x3_scratch_bytes(int Cin, int Cout, size_t* bytes) {
+    RF_CHECK_ARG(bytes && Cin > 0 && Cout > 0, "conv3x3_scratch_bytes: bad arguments");
+    *bytes = packed3x3_floats(Cin, Cout) * sizeof(float);
+    return RF_OK;
+}
+
+int rf_conv3x3(const float* in, float* out, const float* weight, const float* bias, void* scratch,
+               int act, int store, int B, int Cin, int Cout, int h, int w, void* stream) {
+    RF_CHECK_ARG(in && out && weight && scratch && aligned16(scratch), "conv3x3: bad arguments");
+    hipStream_t st = (hipStream_t)stream;
+    RF_TRY(pack_3x3(weight, (float*)scratch, Cout, Cin, st));
+    Conv3x3Args a{};
+    a.x = in; a.x_bstride = (int64_t)Cin * h * w; a.wp = (const float*)scratch; a.bias = bias;
+    a.out = out; a.out_bstride = (int64_t)Cout * h * w; a.B = B; a.Cin = Cin; a.Cout = Cout; a.h = h; a.w = w;
+    a.act = act; a.store = store;
+    return launch_conv3x3(a, st);
+}
+
+int rf_convT2x2_scratch_bytes(int Cin, int Cout, size_t* bytes) {
+    RF_CHECK_ARG(bytes && Cin > 0 && Cout > 0, "convT2x2_scratch_bytes: bad arguments");
+    *bytes = packed1x1_floats(Cin, 4 * Cout) * sizeof(float);
+    return RF_OK;
+}
+
+int rf_convT2x2(const float* in, float* out, const float* weight, const float* bias, void* scratch,
+                int B, int Cin, int Cout, int h, int w, void* stream) {
+    RF_CHECK_ARG(in && out && weight && scratch && aligned16(scratch), "convT2x2: bad arguments");
+    hipStream_t st = (hipStream_t)stream;
+    RF_TRY(pack_convT(weight, (float*)scratch, Cin, Cout, st));
+    Conv1x1Args a{};
+    a.x1 = in; a.C1 = Cin; a.x1_bstride = (int64_t)Cin * h * w; a.wp = (const float*)scratch; a.bias = bias;
+    a.out = out; a.out_bstride = (int64_t)Cout * 4 * h * w; a.Cout = 4 * Cout; a.B = B; a.P = h * w; a.w = w; a.mode = 1;
+    return launch_conv1x1(a, st);
+}
+
+// scratch layout of rf_chan_attn: packed qkv weights | qkv_pre | qkv | gram partials | folded weights
+struct AttnScratch {
+    size_t wqkv, pre, qkv, partial, wfold, total;
+};
+static int attn_scratch(int B, int C, int heads, int P, AttnScratch* s) {
+    int ns, sl;
+    size_t pf;
+    RF_TRY(gram_plan(B, C, heads, P, &ns, &sl, &pf));
+    size_t off = 0;
+    auto take = [&](size_t f) { const size_t o = off; off += align_up(f, 64); return o; };
+    s->wqkv = take(packed1x1_floats(C, 3 * C));
+    s->pre = take((size_t)B * 3 * C * P);
+    s->qkv = take((size_t)B * 3 * C * P);
+    s->partial = take(pf);
+    s->wfold = take((size_t)B * packed1x1_floats(C, C));
+    s->total = off;
+    return RF_OK;
+}
+
+int rf_chan_attn_scratch_bytes(int B, int C, int heads, int h, int w, size_t* bytes) {
+    RF_CHECK_ARG(bytes && B > 0 && C > 0 && heads > 0 && h > 0 && w > 0, "chan_attn_scratch_bytes: bad arguments");
+    AttnScratch s;
+    RF_TRY(attn_scratch(B, C, heads, h * w, &s));
+    *bytes = s.total * sizeof(float);
+    return RF_OK;
+}
+
+int rf_chan_attn(const float* in, float* out, const float* qkv_w, const float* qkv_b,
+                 const float* dw_w, const float* dw_b, const float* temperature,
+                 const float* proj_w, const float* proj_b, void* scratch,
+                 int B, int C, int heads, int h, int w, void* stream) {
+    RF_CHECK_ARG(in && out && qkv_w && dw_w && temperature && proj_w && scratch && aligned16(scratch), "chan_attn: bad arguments");
+    hipStream_t st = (hipStream_t)stream;
+    const int P = h * w;
+    AttnScratch s;
+    RF_TRY(attn_scratch(B, C, heads, P, &s));
+    float* ws = (float*)scratch;
+    RF_TRY(pack_1x1(qkv_w, ws + s.wqkv, 3 * C, C, C, 1, st));
+    Conv1x1Args q{};
+    q.x1 = in; q.C1 = C; q.x1_bstride = (int64_t)C * P; q.wp = ws + s.wqkv; q.bias = qkv_b;
+    q.out = ws + s.pre; q.out_bstride = (int64_t)3 * C * P; q.Cout = 3 * C; q.B = B; q.P = P; q.w = w;
+    RF_TRY(launch_conv1x1(q, st));
+    DwConvArgs d{};
+    d.x = ws + s.pre; d.x_bstride = (int64_t)3 * C * P; d.out = ws + s.qkv; d.out_bstride = (int64_t)3 * C * P;
+    d.w = dw_w; d.bias = dw_b; d.B = B; d.C = 3 * C; d.h = h; d.w_ = w;
+    RF_TRY(launch_dwconv3x3(d, st));
+    GramArgs g{};
+    g.q = ws + s.qkv; g.k = ws + s.qkv + (size_t)C * P; g.bstride = (int64_t)3 * C * P;
+    g.B = B; g.C = C; g.heads = heads; g.P = P; g.partial = ws + s.partial;
+    size_t pf;
+    RF_TRY(gram_plan(B, C, heads, P, &g.nslab, &g.slab, &pf));
+    RF_TRY(launch_gram(g, st));
+    RF_TRY(launch_attn_fold(g.partial, g.nslab, temperature, proj_w, ws + s.wfold, B, C, heads, st));
+    Conv1x1Args av{};
+    av.x1 = ws + s.qkv + (size_t)2 * C * P; av.C1 = C; av.x1_bstride = (int64_t)3 * C * P;
+    av.wp = ws + s.wfold; av.wp_bstride = (int64_t)packed1x1_floats(C, C); av.bias = proj_b;
+    av.out = out; av.out_bstride = (int64_t)C * P; av.Cout = C; av.B = B; av.P = P; av.w = w;
+    return launch_conv1x1(av, st);
+}
+
+int rf_guidance_scratch_bytes(int B, int H, int W, size_t* bytes) {
+    RF_CHECK_ARG(bytes && B > 0 && H > 0 && W > 0, "guidance_scratch_bytes: bad arguments");
+    *bytes = guidance_scratch_floats(B, H, W) * sizeof(float);
+    return RF_OK;
+}
+
+int rf_flca_guidance(const float* packed, float* guide, void* scratch, int B, int H, int W, int hf, int wf, void* stream) {
+    RF_CHECK_ARG(packed && guide && scratch && hf > 0 && wf > 0, "flca_guidance: bad arguments");
+    hipStream_t st = (hipStream_t)stream;
+    RF_TRY(launch_guidance_base(packed, 0, 0, (float*)scratch, B, H, W, st));
+    return launch_guidance_level((const float*)scratch, guide, B, H, W, hf, wf, st);
+}
+
+}  // extern "C"

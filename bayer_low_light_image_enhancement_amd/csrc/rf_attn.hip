@@ -1,0 +1,216 @@
+// Channel ("transposed") attention, a5: the c x c attention map of each head is built from
+// L2-normalised q and k rows, so the expensive part is two reductions over all N pixels:
+//   G[i][j] = sum_n q_i[n] k_j[n],   |q_i|^2,   |k_j|^2.
+// gram_kernel streams q and k once (HBM-bound, c/4 flop per byte) and forms 16x16 Gram tiles with
+// v_mfma_f32_16x16x4_f32, the pixel axis being the MFMA K dimension.  The row norms are the
+// diagonals of q q^T and k k^T and reuse the SAME registers as A and B operand (for this
+// instruction A[i][k] and B[k][j] have the same lane map), so they cost one extra MFMA each.
+// Pixel slabs are reduced through per-slab partials (no float atomics: results are bitwise
+// reproducible run to run).
+// attn_fold_kernel finishes the softmax and folds it into project_out:
+//   project_out(attn @ v) = (W_out * blockdiag(attn_b)) v,
+// a per-image C x C matrix written directly in MFMA operand order, so attn @ v and the 1x1
+// projection become ONE GEMM over v (rf_conv1x1.hip) instead of two more passes over N.
+#include "rf_common.h"
+
+namespace rf {
+
+static constexpr int kMaxBand = 4;            // k tiles a q tile can need (head size <= 64)
+static constexpr int kRowW = kMaxBand * 16 + 2;   // partial row: band columns, |q|^2, |k|^2
+
+__host__ __device__ static inline void band_of(int tq, int C, int c, int* tklo, int* nb) {
+    const int lo_ch = 16 * tq;
+    const int hi_ch = (16 * tq + 15 < C - 1) ? 16 * tq + 15 : C - 1;
+    const int hlo = lo_ch / c, hhi = hi_ch / c;
+    const int klo = hlo * c, khi = (hhi + 1) * c - 1;
+    *tklo = klo / 16;
+    *nb = khi / 16 - *tklo + 1;
+}
+
+int gram_plan(int B, int C, int heads, int P, int* nslab, int* slab, size_t* partial_floats) {
+    RF_CHECK_ARG(heads > 0 && C % heads == 0, "chan_attn: C=%d not divisible by heads=%d", C, heads);
+    const int c = C / heads;
+    RF_CHECK_ARG(c <= 64, "chan_attn: head size %d > 64 not supported", c);
+    const int NTq = cdiv(C, 16);
+    // the slab split depends only on (C, P), never on B: an image's result is bitwise the same
+    // alone and inside a batch
+    int ns = cdiv(256, NTq);
+    const int maxs = cdiv(P, 256);
+    if (ns > maxs) ns = maxs;
+    if (ns < 1) ns = 1;
+    int sl = cdiv(cdiv(P, ns), 256) * 256;
+    ns = cdiv(P, sl);
+    *nslab = ns;
+    *slab = sl;
+    *partial_floats = (size_t)B * ns * NTq * 16 * kRowW;
+    return RF_OK;
+}
+
+__global__ void __launch_bounds__(256) gram_kernel(GramArgs a, int vec) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int i = lane & 15, kq = lane >> 4;
+    const int slab_id = blockIdx.x, tq = blockIdx.y, b = blockIdx.z;
+    const int C = a.C, P = a.P, c = C / a.heads;
+    int tklo, nb;
+    band_of(tq, C, c, &tklo, &nb);
+    const float* qb = a.q + (size_t)b * a.bstride;
+    const float* kb = a.k + (size_t)b * a.bstride;
+    const int n_lo = slab_id * a.slab;
+    const int n_hi = (n_lo + a.slab < P) ? n_lo + a.slab : P;
+
+    f32x4 g[kMaxBand], nq = {0.f, 0.f, 0.f, 0.f}, nk = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int t = 0; t < kMaxBand; ++t) g[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    auto load4 = [&](const float* base, int ch, int n) -> float4 {
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (ch < C) {
+            const float* p = base + (size_t)ch * P + n;
+            if (vec) {
+                if (n < n_hi) v = *reinterpret_cast<const float4*>(p);
+            } else {
+                if (n < n_hi) v.x = p[0];
+                if (n + 1 < n_hi) v.y = p[1];
+                if (n + 2 < n_hi) v.z = p[2];
+                if (n + 3 < n_hi) v.w = p[3];
+            }
+        }
+        return v;
+    };
+
+    // a wave step covers 16 pixels: lane (i, kq) holds pixels n + 4kq .. 4kq+3 of channel row i
+    for (int n = n_lo + wave * 16; n < n_hi; n += 64) {
+        const int nn = n + 4 * kq;
+        const float4 qv = load4(qb, 16 * tq + i, nn);
+        float4 kv[kMaxBand];
+#pragma unroll
+        for (int t = 0; t < kMaxBand; ++t)
+            kv[t] = (t < nb) ? load4(kb, 16 * (tklo + t) + i, nn) : make_float4(0.f, 0.f, 0.f, 0.f);
+        const float4 kd = load4(kb, 16 * tq + i, nn);   // k rows of the diagonal tile (for |k|^2)
+        const float qa[4] = {qv.x, qv.y, qv.z, qv.w};
+        const float ka[4] = {kd.x, kd.y, kd.z, kd.w};
+#pragma unroll
+        for (int m = 0; m < 4; ++m) {
+            nq = __builtin_amdgcn_mfma_f32_16x16x4f32(qa[m], qa[m], nq, 0, 0, 0);
+            nk = __builtin_amdgcn_mfma_f32_16x16x4f32(ka[m], ka[m], nk, 0, 0, 0);
+        }
+#pragma unroll
+        for (int t = 0; t < kMaxBand; ++t) {
+            if (t < nb) {
+                const float kt[4] = {kv[t].x, kv[t].y, kv[t].z, kv[t].w};
+#pragma unroll
+                for (int m = 0; m < 4; ++m) g[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(qa[m], kt[m], g[t], 0, 0, 0);
+            }
+        }
+    }
+
+    // cross-wave reduction in a fixed order, then one plain store per value
+    __shared__ float red[4][16][kRowW];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int row = 4 * kq + r;
+#pragma unroll
+        for (int t = 0; t < kMaxBand; ++t) red[wave][row][t * 16 + i] = g[t][r];
+        if (row == i) {
+            red[wave][row][kMaxBand * 16] = nq[r];
+            red[wave][row][kMaxBand * 16 + 1] = nk[r];
+        }
+    }
+    __syncthreads();
+    float* dst = a.partial + (((size_t)b * a.nslab + slab_id) * gridDim.y + tq) * 16 * kRowW;
+    for (int idx = threadIdx.x; idx < 16 * kRowW; idx += 256) {
+        const int row = idx / kRowW, col = idx % kRowW;
+        dst[idx] = ((red[0][row][col] + red[1][row][col]) + red[2][row][col]) + red[3][row][col];
+    }
+}
+
+int launch_gram(const GramArgs& a, hipStream_t st) {
+    RF_CHECK_ARG(a.B > 0 && a.B <= 65535 && a.C > 0 && a.P > 0, "gram: bad sizes");
+    const int vec = (a.P % 4 == 0) && aligned16(a.q) && aligned16(a.k) && (a.bstride % 4 == 0);
+    dim3 grid((unsigned)a.nslab, (unsigned)cdiv(a.C, 16), (unsigned)a.B);
+    const double c = (double)a.C / a.heads;
+    ProfScope prof(st, "gram_kernel", 2.0 * a.C * c * a.P * a.B, 8.0 * a.C * (double)a.P * a.B);
+    gram_kernel<<<grid, 256, 0, st>>>(a, vec);
+    return check_launch("gram");
+}
+
+// one workgroup per (head, image)
+__global__ void __launch_bounds__(256) attn_fold_kernel(const float* __restrict__ partial, int nslab,
+                                                        const float* __restrict__ temperature,
+                                                        const float* __restrict__ w_out, float* __restrict__ wp_out,
+                                                        int C, int heads) {
+    const int hd = blockIdx.x, b = blockIdx.y;
+    const int c = C / heads;
+    const int NT = (C + 15) >> 4;
+    __shared__ float S[64][65];
+    __shared__ float nq[64], nk[64];
+    const float* pb = partial + (size_t)b * nslab * NT * 16 * kRowW;
+    // 1. reduce the slab partials (fixed order)
+    for (int idx = threadIdx.x; idx < c * c + 2 * c; idx += 256) {
+        int qch, col;
+        if (idx < c * c) {
+            const int ii = idx / c, jj = idx % c;
+            qch = hd * c + ii;
+            const int kch = hd * c + jj;
+            int tklo, nb;
+            band_of(qch >> 4, C, c, &tklo, &nb);
+            col = ((kch >> 4) - tklo) * 16 + (kch & 15);
+        } else if (idx < c * c + c) {
+            qch = hd * c + (idx - c * c);
+            col = kMaxBand * 16;
+        } else {
+            qch = hd * c + (idx - c * c - c);
+            col = kMaxBand * 16 + 1;
+        }
+        const float* src = pb + ((size_t)(qch >> 4) * 16 + (qch & 15)) * kRowW + col;
+        float s = 0.f;
+        for (int sl = 0; sl < nslab; ++sl) s += src[(size_t)sl * NT * 16 * kRowW];
+        if (idx < c * c) S[idx / c][idx % c] = s;
+        else if (idx < c * c + c) nq[idx - c * c] = s;
+        else nk[idx - c * c - c] = s;
+    }
+    __syncthreads();
+    // 2. cosine similarity * temperature, softmax over j (F.normalize clamps the norm at 1e-12)
+    if (threadIdx.x < c) {
+        const int ii = threadIdx.x;
+        const float T = temperature[hd];
+        const float rq = 1.0f / fmaxf(sqrtf(nq[ii]), 1e-12f);
+        float m = -INFINITY;
+        for (int jj = 0; jj < c; ++jj) {
+            const float v = S[ii][jj] * rq * (1.0f / fmaxf(sqrtf(nk[jj]), 1e-12f)) * T;
+            S[ii][jj] = v;
+            m = fmaxf(m, v);
+        }
+        float sum = 0.f;
+        for (int jj = 0; jj < c; ++jj) {
+            const float e = expf(S[ii][jj] - m);
+            S[ii][jj] = e;
+            sum += e;
+        }
+        const float inv = 1.0f / sum;
+        for (int jj = 0; jj < c; ++jj) S[ii][jj] *= inv;
+    }
+    __syncthreads();
+    // 3. W'[co][hd*c + j] = sum_i W_out[co][hd*c + i] * attn[i][j], stored in MFMA operand order
+    float* dst = wp_out + (size_t)b * NT * (C / 4) * 64;
+    for (int idx = threadIdx.x; idx < NT * 16 * c; idx += 256) {
+        const int co = idx / c, jj = idx % c;
+        float s = 0.f;
+        if (co < C) {
+            const float* wr = w_out + (size_t)co * C + hd * c;
+            for (int ii = 0; ii < c; ++ii) s = fmaf(wr[ii], S[ii][jj], s);
+        }
+        const int k = hd * c + jj;
+        dst[((size_t)(k >> 2) * NT + (co >> 4)) * 64 + (co & 15) + 16 * (k & 3)] = s;
+    }
+}
+
+int launch_attn_fold(const float* partial, int nslab, const float* temperature, const float* w_out,
+                     float* wp_out, int B, int C, int heads, hipStream_t st) {
+    RF_CHECK_ARG(C % heads == 0 && C / heads <= 64 && C % 4 == 0, "attn_fold: unsupported C=%d heads=%d", C, heads);
+    ProfScope prof(st, "attn_fold_kernel", 0.0, 0.0);
+    attn_fold_kernel<<<dim3((unsigned)heads, (unsigned)B), 256, 0, st>>>(partial, nslab, temperature, w_out, wp_out, C, heads);
+    return check_launch("attn_fold");
+}
+
+}  // namespace rf

@@ -1,0 +1,156 @@
+// Shared declarations for the gfx950 RawFormer kernels (internal; the public ABI is
+// include/rawformer_hip.h).  Everything here is written for CDNA4 only: 64-lane waves,
+// v_mfma_f32_16x16x4_f32, 160 KB LDS.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stddef.h>
+#include "../../include/rawformer_hip.h"
+
+namespace rf {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+void set_error(const char* fmt, ...);
+int check_hip(hipError_t e, const char* what);
+int check_launch(const char* what);
+
+#define RF_CHECK_ARG(cond, ...)            \
+    do {                                   \
+        if (!(cond)) {                     \
+            rf::set_error(__VA_ARGS__);    \
+            return RF_E_INVALID;           \
+        }                                  \
+    } while (0)
+
+// Optional per-launch HIP-event bracket (rf_profile_begin / rf_profile_end in the C ABI):
+// bench.py uses it to time each kernel class on the stream it is launched on.
+struct ProfScope {
+    ProfScope(hipStream_t st, const char* key, double flops, double bytes);
+    ~ProfScope();
+    hipStream_t st_;
+    int rec_;
+};
+
+static inline int cdiv(int a, int b) { return (a + b - 1) / b; }
+static inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+static inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
+
+// ---------------------------------------------------------------------------------------------
+// MFMA operand packing.  All dense contractions use v_mfma_f32_16x16x4_f32:
+//   A (weights)   lane l holds A[i = l & 15][k = l >> 4]
+//   B (pixels)    lane l holds B[k = l >> 4][j = l & 15]
+//   C/D           lane l, reg r holds D[row = 4 * (l >> 4) + r][col = l & 15]
+// A packed weight matrix [Cout][K] is stored as tiles of 64 floats in lane order:
+//   packed[(s * NT + t) * 64 + l] = W[16 t + (l & 15)][4 s + (l >> 4)]      (zero outside)
+// with NT = ceil(Cout / 16) and s over ceil(K / 4) k-sets.  A 3x3 weight [Cout][Cin][3][3] is
+//   packed[((s * 9 + tap) * NT + t) * 64 + l] = W[16 t + (l & 15)][4 s + (l >> 4)][tap].
+// ---------------------------------------------------------------------------------------------
+static inline size_t packed1x1_floats(int K, int Cout) { return (size_t)cdiv(K, 4) * cdiv(Cout, 16) * 64; }
+static inline size_t packed3x3_floats(int Cin, int Cout) { return (size_t)cdiv(Cin, 8) * 2 * 9 * cdiv(Cout, 16) * 64; }
+
+// ---- weight repacking (rf_pack.hip)
+// 1x1: W[Cout][K] row-major -> packed.  `row_stride`/`col_stride` let the source be a
+// ConvTranspose2d weight [Cin][Cout][2][2] viewed as rows (o,i,j) x cols k.
+int pack_1x1(const float* w, float* packed, int Cout, int K, int64_t row_stride, int64_t col_stride, hipStream_t st);
+int pack_3x3(const float* w, float* packed, int Cout, int Cin, hipStream_t st);
+int pack_convT(const float* w, float* packed, int Cin, int Cout, hipStream_t st);
+
+// ---- conv1x1 (rf_conv1x1.hip)
+struct Conv1x1Args {
+    const float* x1;       // first source, channel 0 of image 0
+    const float* x2;       // second source or nullptr
+    int C1, C2;            // channels taken from each source (K = C1 + C2)
+    int64_t x1_bstride;    // floats between images in source 1
+    int64_t x2_bstride;
+    const float* wp;       // packed weights
+    int64_t wp_bstride;    // floats between per-image weight sets (0 = shared)
+    const float* bias;     // [Cout] or nullptr
+    const float* ln_w;     // LayerNorm prologue over the K channels (nullptr = none)
+    const float* ln_b;
+    float ln_eps;
+    const float* res;      // residual, same layout as out (nullptr = none)
+    int64_t res_bstride;
+    float* out;
+    int64_t out_bstride;
+    int Cout;              // rows of W (for mode 1: 4 * output channels)
+    int B, P;              // images, pixels per image
+    int w;                 // image width (mode 1 only)
+    int mode;              // 0: out[co][p]; 1: ConvTranspose2d 2x2 scatter, row co = 4*o + 2*i + j
+    int act;               // 0 none, 1 LeakyReLU(0.2)
+};
+int launch_conv1x1(const Conv1x1Args& a, hipStream_t st);
+
+// ---- conv3x3 (rf_conv3x3.hip)
+struct Conv3x3Args {
+    const float* x;        // [B][Cin][h][w]; with unshuffle_in: mosaic [B][Cin/4][2h][2w]
+    int64_t x_bstride;
+    const float* wp;       // packed 3x3 weights
+    const float* bias;     // [Cout] or nullptr
+    float* out;
+    int64_t out_bstride;
+    int B, Cin, Cout, h, w;
+    int act;               // 0 none, 1 LeakyReLU(0.2)
+    int store;             // 0 plain, 1 pixel-unshuffle, 2 pixel-shuffle
+    int unshuffle_in;      // read the input through the Bayer pack (a1)
+    int clamp_in;          // clamp input to [0,1] while loading
+    int clamp_out;         // clamp output to [0,1] before storing
+};
+int launch_conv3x3(const Conv3x3Args& a, hipStream_t st);
+
+// ---- memory-bound ops (rf_pointwise.hip)
+int launch_layernorm2d(const float* in, float* out, const float* w, const float* b, float eps,
+                       int B, int C, int P, hipStream_t st);
+struct DwConvArgs {
+    const float* x; int64_t x_bstride;
+    float* out; int64_t out_bstride;
+    const float* w;        // [C][9]
+    const float* bias;     // [C] or nullptr
+    int B, C, h, w_;
+    int gelu;
+};
+int launch_dwconv3x3(const DwConvArgs& a, hipStream_t st);
+int launch_pixel_unshuffle2(const float* in, float* out, int B, int C, int h, int w, hipStream_t st);
+int launch_pixel_shuffle2(const float* in, float* out, int B, int C, int h, int w, hipStream_t st);
+// 2x2 analysis/synthesis with an arbitrary 4x4 matrix.  layout 0: bands on the batch axis
+// (dwt_init), 1: band-major channels (CustomDWT), 2: four separate [B,C,h,w] planes (HaarDWT).
+// exact_haar selects the reference's summation order for dwt_init / iwt_init (bit-exact).
+int launch_dwt2x2(const float* in, float* out, const float k[16], int layout, int exact_haar,
+                  int B, int C, int h, int w, int hin, int win, hipStream_t st);
+int launch_idwt2x2(const float* in, float* out, const float k[16], int layout, int exact_haar,
+                   int B, int C, int h, int w, hipStream_t st);
+
+// ---- channel attention (rf_attn.hip)
+struct GramArgs {
+    const float* q; const float* k;   // channel 0 of image 0 for q and k
+    int64_t bstride;                  // floats between images
+    int B, C, heads, P;
+    float* partial;                   // [B][nslab][C][bandw + 2]  (see gram_partial_floats)
+    int nslab, slab;
+};
+int gram_plan(int B, int C, int heads, int P, int* nslab, int* slab, size_t* partial_floats);
+int launch_gram(const GramArgs& a, hipStream_t st);
+// softmax + fold into project_out: wp_out[b] = pack(W_out * blockdiag(attn_b))
+int launch_attn_fold(const float* partial, int nslab, const float* temperature, const float* w_out,
+                     float* wp_out, int B, int C, int heads, hipStream_t st);
+
+// ---- FLCA (rf_flca.hip)
+size_t guidance_scratch_floats(int B, int H, int W);
+// packed-or-mosaic input -> base planes in scratch (y, cr, cb at HxW; LL, mag at H/2 x W/2)
+int launch_guidance_base(const float* in, int mosaic, int clamp_in, float* scratch, int B, int H, int W, hipStream_t st);
+int launch_guidance_level(const float* scratch, float* guide, int B, int H, int W, int hf, int wf, hipStream_t st);
+struct FlcaSpatialArgs {
+    const float* feat; float* xs; const float* guide;   // feat/xs [B][C][P], guide [B][4][h][w]
+    const float* w_low; const float* w_high; const float* w_chr;   // [C][1][3][3], [C][1][3][3], [C][2][3][3]
+    const float* alpha; const float* beta; const float* gamma;     // device scalars
+    float* partial;                                      // [B][nblk][C] per-block channel sums
+    int B, C, h, w, nblk;
+};
+int flca_nblk(int h, int w);
+int launch_flca_spatial(const FlcaSpatialArgs& a, hipStream_t st);
+// SE + fold into channel_reduce: wp_out[b] = pack([Wa * diag(ch_b) | Wb])
+int launch_flca_se_fold(const float* partial, int nblk, int P, const float* se1_w, const float* se1_b,
+                        const float* se3_w, const float* se3_b, int hidden, const float* w_cr,
+                        float* wp_out, float* ch_out, int B, int C, hipStream_t st);
+
+}  // namespace rf

@@ -1,0 +1,266 @@
+// FLCA branch (a15, FrequencyawareLumaChromaAttentionRAWFormer.py:79-162) and its guidance.
+//   guidance_base : packed RGGB (or the mosaic itself) -> y, cr, cb at HxW, Haar LL and
+//                   high-band magnitude at H/2 x W/2 (a14 on the 1-channel luma)
+//   guidance_level: bilinear resize (align_corners=False) of those planes to a stage size
+//   flca_spatial  : feat * (1 + a*sigmoid(conv3(y_low)) + b*tanh(conv3(y_high)) + g*sigmoid(conv3(cr,cb)))
+//                   + per-block channel sums for the squeeze-excite pooling
+//   flca_se_fold  : SE MLP, then folds the per-image channel gate into the following
+//                   channel_reduce 1x1:  W_cr [x*ch ; trans] = [W_a diag(ch) | W_b] [x ; trans]
+#include "rf_common.h"
+
+namespace rf {
+
+size_t guidance_scratch_floats(int B, int H, int W) {
+    const size_t hw = (size_t)H * W;
+    return (size_t)B * (3 * hw + 2 * (hw / 4)) + align_up((size_t)B, 64);
+}
+
+struct GuideLayout {
+    float *y, *cr, *cb, *ll, *mag;
+    int* amax;
+};
+__host__ __device__ static inline GuideLayout guide_layout(float* s, int B, int H, int W) {
+    const size_t hw = (size_t)H * W;
+    GuideLayout g;
+    g.y = s;
+    g.cr = g.y + B * hw;
+    g.cb = g.cr + B * hw;
+    g.ll = g.cb + B * hw;
+    g.mag = g.ll + B * (hw / 4);
+    g.amax = reinterpret_cast<int*>(g.mag + B * (hw / 4));
+    return g;
+}
+
+__device__ __forceinline__ void atomic_max_float(int* addr, float v) {
+    if (v >= 0.f) atomicMax(addr, __float_as_int(v));
+    else atomicMin(reinterpret_cast<unsigned int*>(addr), __float_as_uint(v));
+}
+
+__device__ __forceinline__ float packed_at(const float* in, int mosaic, int clamp_in, size_t b, int ch, int y, int x, int H, int W) {
+    float v = mosaic ? in[(b * 2 * H + 2 * y + (ch >> 1)) * (size_t)(2 * W) + 2 * x + (ch & 1)]
+                     : in[((b * 4 + ch) * H + y) * (size_t)W + x];
+    return clamp_in ? fminf(fmaxf(v, 0.f), 1.f) : v;
+}
+
+__global__ void guide_init_kernel(int* amax, int B) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < B) amax[i] = (int)0xff800000u;   // -inf
+}
+
+// y_raw = 0.299 R + 0.587 * 0.5 (G1 + G2) + 0.114 B and its per-image maximum
+__global__ void __launch_bounds__(256) guide_luma_kernel(const float* __restrict__ in, int mosaic, int clamp_in,
+                                                         float* __restrict__ yraw, int* __restrict__ amax, int H, int W) {
+    const size_t b = blockIdx.y;
+    const size_t hw = (size_t)H * W;
+    float m = -INFINITY;
+    for (size_t p = blockIdx.x * 256ull + threadIdx.x; p < hw; p += (size_t)gridDim.x * 256) {
+        const int y = (int)(p / W), x = (int)(p % W);
+        const float r = packed_at(in, mosaic, clamp_in, b, 0, y, x, H, W);
+        const float g = 0.5f * (packed_at(in, mosaic, clamp_in, b, 1, y, x, H, W) + packed_at(in, mosaic, clamp_in, b, 2, y, x, H, W));
+        const float bl = packed_at(in, mosaic, clamp_in, b, 3, y, x, H, W);
+        const float v = (0.299f * r + 0.587f * g) + 0.114f * bl;
+        yraw[b * hw + p] = v;
+        m = fmaxf(m, v);
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+    if ((threadIdx.x & 63) == 0 && m > -INFINITY) atomic_max_float(amax + b, m);
+}
+
+// normalise luma, chroma differences, Haar LL / high-band magnitude (one thread per 2x2 block)
+__global__ void __launch_bounds__(256) guide_haar_kernel(const float* __restrict__ in, int mosaic, int clamp_in, float* __restrict__ scratch,
+                                                         int B, int H, int W) {
+    const GuideLayout g = guide_layout(scratch, B, H, W);
+    const size_t b = blockIdx.y;
+    const int H2 = H / 2, W2 = W / 2;
+    const size_t hw = (size_t)H * W, hw4 = (size_t)H2 * W2;
+    const float inv = 1.0f / fmaxf(__int_as_float(g.amax[b]), 1e-6f);
+    for (size_t q = blockIdx.x * 256ull + threadIdx.x; q < hw4; q += (size_t)gridDim.x * 256) {
+        const int y2 = (int)(q / W2), x2 = (int)(q % W2);
+        float yv[4];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            const int y = 2 * y2 + (t >> 1), x = 2 * x2 + (t & 1);
+            const size_t p = (size_t)y * W + x;
+            const float yn = g.y[b * hw + p] * inv;
+            g.y[b * hw + p] = yn;
+            g.cr[b * hw + p] = packed_at(in, mosaic, clamp_in, b, 0, y, x, H, W) - yn;
+            g.cb[b * hw + p] = packed_at(in, mosaic, clamp_in, b, 3, y, x, H, W) - yn;
+            yv[t] = yn;
+        }
+        const float ll = (yv[0] + yv[1] + yv[2] + yv[3]) * 0.5f;
+        const float lh = (yv[0] - yv[1] + yv[2] - yv[3]) * 0.5f;
+        const float hl = (yv[0] + yv[1] - yv[2] - yv[3]) * 0.5f;
+        const float hh = (yv[0] - yv[1] - yv[2] + yv[3]) * 0.5f;
+        g.ll[b * hw4 + q] = ll;
+        g.mag[b * hw4 + q] = sqrtf(lh * lh + hl * hl + hh * hh + 1e-8f);
+    }
+}
+
+int launch_guidance_base(const float* in, int mosaic, int clamp_in, float* scratch, int B, int H, int W, hipStream_t st) {
+    RF_CHECK_ARG(H % 2 == 0 && W % 2 == 0 && B <= 65535, "guidance: H=%d W=%d must be even", H, W);
+    const GuideLayout g = guide_layout(scratch, B, H, W);
+    ProfScope prof(st, "guidance_base(3 kernels)", 0.0, 4.0 * B * H * W * (4 + 1 + 1 + 4 + 3.5));
+    guide_init_kernel<<<cdiv(B, 256), 256, 0, st>>>(g.amax, B);
+    const size_t hw = (size_t)H * W;
+    int gx = (int)((hw + 255) / 256);
+    if (gx > 1024) gx = 1024;
+    guide_luma_kernel<<<dim3((unsigned)gx, (unsigned)B), 256, 0, st>>>(in, mosaic, clamp_in, g.y, g.amax, H, W);
+    int gx2 = (int)((hw / 4 + 255) / 256);
+    if (gx2 > 1024) gx2 = 1024;
+    guide_haar_kernel<<<dim3((unsigned)gx2, (unsigned)B), 256, 0, st>>>(in, mosaic, clamp_in, scratch, B, H, W);
+    return check_launch("guidance_base");
+}
+
+// F.interpolate(mode='bilinear', align_corners=False)
+__device__ __forceinline__ float bilerp(const float* __restrict__ src, int hi, int wi, int ho, int wo, int y, int x) {
+    const float sy = fmaxf(((float)y + 0.5f) * ((float)hi / (float)ho) - 0.5f, 0.f);
+    const float sx = fmaxf(((float)x + 0.5f) * ((float)wi / (float)wo) - 0.5f, 0.f);
+    int y0 = (int)sy, x0 = (int)sx;
+    if (y0 > hi - 1) y0 = hi - 1;
+    if (x0 > wi - 1) x0 = wi - 1;
+    const int y1 = y0 + (y0 < hi - 1), x1 = x0 + (x0 < wi - 1);
+    const float ly = sy - (float)y0, lx = sx - (float)x0;
+    const float top = src[(size_t)y0 * wi + x0] * (1.f - lx) + src[(size_t)y0 * wi + x1] * lx;
+    const float bot = src[(size_t)y1 * wi + x0] * (1.f - lx) + src[(size_t)y1 * wi + x1] * lx;
+    return top * (1.f - ly) + bot * ly;
+}
+
+__global__ void __launch_bounds__(256) guide_level_kernel(const float* __restrict__ scratch, float* __restrict__ guide,
+                                                          int B, int H, int W, int hf, int wf) {
+    const GuideLayout g = guide_layout(const_cast<float*>(scratch), B, H, W);
+    const size_t b = blockIdx.y;
+    const size_t pf = (size_t)hf * wf, hw = (size_t)H * W;
+    for (size_t p = blockIdx.x * 256ull + threadIdx.x; p < pf; p += (size_t)gridDim.x * 256) {
+        const int y = (int)(p / wf), x = (int)(p % wf);
+        float* o = guide + b * 4 * pf + p;
+        o[0] = bilerp(g.ll + b * (hw / 4), H / 2, W / 2, hf, wf, y, x);
+        o[pf] = bilerp(g.mag + b * (hw / 4), H / 2, W / 2, hf, wf, y, x);
+        o[2 * pf] = bilerp(g.cr + b * hw, H, W, hf, wf, y, x);
+        o[3 * pf] = bilerp(g.cb + b * hw, H, W, hf, wf, y, x);
+    }
+}
+
+int launch_guidance_level(const float* scratch, float* guide, int B, int H, int W, int hf, int wf, hipStream_t st) {
+    int gx = cdiv(hf * wf, 256);
+    if (gx > 1024) gx = 1024;
+    ProfScope prof(st, "guide_level_kernel", 0.0, 4.0 * B * hf * wf * 8);
+    guide_level_kernel<<<dim3((unsigned)gx, (unsigned)B), 256, 0, st>>>(scratch, guide, B, H, W, hf, wf);
+    return check_launch("guidance_level");
+}
+
+// ------------------------------------------------------------------------------------------
+int flca_nblk(int h, int w) { return cdiv(h * w, 256); }
+
+__global__ void __launch_bounds__(256) flca_spatial_kernel(FlcaSpatialArgs a) {
+    const int blk = blockIdx.x;
+    const size_t b = blockIdx.y;
+    const int h = a.h, w = a.w, P = h * w, C = a.C;
+    const int p = blk * 256 + threadIdx.x;
+    const bool live = p < P;
+    const int y = live ? p / w : 0, x = live ? p % w : 0;
+    // 3x3 neighbourhoods of the four guidance planes, zero padded
+    float nb[4][9];
+    const float* gb = a.guide + b * 4 * (size_t)P;
+#pragma unroll
+    for (int pl = 0; pl < 4; ++pl)
+#pragma unroll
+        for (int dy = 0; dy < 3; ++dy)
+#pragma unroll
+            for (int dx = 0; dx < 3; ++dx) {
+                const int yy = y + dy - 1, xx = x + dx - 1;
+                nb[pl][dy * 3 + dx] = (live && yy >= 0 && yy < h && xx >= 0 && xx < w) ? gb[(size_t)pl * P + (size_t)yy * w + xx] : 0.f;
+            }
+    const float al = *a.alpha, be = *a.beta, ga = *a.gamma;
+    __shared__ float red[512][4];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const float* fb = a.feat + b * (size_t)C * P;
+    float* xb = a.xs + b * (size_t)C * P;
+    for (int c = 0; c < C; ++c) {
+        const float* wl = a.w_low + c * 9;
+        const float* wh = a.w_high + c * 9;
+        const float* wc = a.w_chr + c * 18;
+        float sl = 0.f, sh = 0.f, sc = 0.f;
+#pragma unroll
+        for (int t = 0; t < 9; ++t) {
+            sl = fmaf(wl[t], nb[0][t], sl);
+            sh = fmaf(wh[t], nb[1][t], sh);
+            sc = fmaf(wc[t], nb[2][t], sc);
+        }
+#pragma unroll
+        for (int t = 0; t < 9; ++t) sc = fmaf(wc[9 + t], nb[3][t], sc);
+        const float a_low = 1.0f / (1.0f + expf(-sl));
+        const float a_high = tanhf(sh);
+        const float a_chr = 1.0f / (1.0f + expf(-sc));
+        const float spatial = 1.0f + al * a_low + be * a_high + ga * a_chr;
+        float v = 0.f;
+        if (live) {
+            v = fb[(size_t)c * P + p] * spatial;
+            xb[(size_t)c * P + p] = v;
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+        if (lane == 0) red[c][wave] = v;
+    }
+    __syncthreads();
+    for (int c = threadIdx.x; c < C; c += 256)
+        a.partial[(b * a.nblk + blk) * C + c] = (red[c][0] + red[c][1]) + (red[c][2] + red[c][3]);
+}
+
+int launch_flca_spatial(const FlcaSpatialArgs& a, hipStream_t st) {
+    RF_CHECK_ARG(a.C <= 512 && a.B <= 65535, "flca: C=%d > 512 not supported", a.C);
+    const double el = (double)a.B * a.C * a.h * a.w;
+    ProfScope prof(st, "flca_spatial_kernel", 80.0 * el, 8.0 * el);
+    flca_spatial_kernel<<<dim3((unsigned)a.nblk, (unsigned)a.B), 256, 0, st>>>(a);
+    return check_launch("flca_spatial");
+}
+
+__global__ void __launch_bounds__(256) flca_se_fold_kernel(const float* __restrict__ partial, int nblk, int P,
+                                                           const float* __restrict__ se1_w, const float* __restrict__ se1_b,
+                                                           const float* __restrict__ se3_w, const float* __restrict__ se3_b, int hidden,
+                                                           const float* __restrict__ w_cr, float* __restrict__ wp_out,
+                                                           float* __restrict__ ch_out, int C) {
+    const size_t b = blockIdx.x;
+    __shared__ float mean[512], hid[64], ch[512];
+    for (int c = threadIdx.x; c < C; c += 256) {
+        const float* src = partial + b * nblk * C + c;
+        float s = 0.f;
+        for (int k = 0; k < nblk; ++k) s += src[(size_t)k * C];
+        mean[c] = s / (float)P;
+    }
+    __syncthreads();
+    for (int m = threadIdx.x; m < hidden; m += 256) {
+        float s = se1_b[m];
+        for (int c = 0; c < C; ++c) s = fmaf(se1_w[m * C + c], mean[c], s);
+        hid[m] = fmaxf(s, 0.f);
+    }
+    __syncthreads();
+    for (int c = threadIdx.x; c < C; c += 256) {
+        float s = se3_b[c];
+        for (int m = 0; m < hidden; ++m) s = fmaf(se3_w[c * hidden + m], hid[m], s);
+        const float v = 1.0f / (1.0f + expf(-s));
+        ch[c] = v;
+        if (ch_out) ch_out[b * C + c] = v;
+    }
+    __syncthreads();
+    const int NT = (C + 15) >> 4, NS = (2 * C) >> 2;
+    float* dst = wp_out + b * (size_t)NT * NS * 64;
+    for (int idx = threadIdx.x; idx < NT * NS * 64; idx += 256) {
+        const int l = idx & 63, t = (idx >> 6) % NT, s = (idx >> 6) / NT;
+        const int co = 16 * t + (l & 15), k = 4 * s + (l >> 4);
+        float v = 0.f;
+        if (co < C) v = w_cr[(size_t)co * 2 * C + k] * (k < C ? ch[k] : 1.0f);
+        dst[idx] = v;
+    }
+}
+
+int launch_flca_se_fold(const float* partial, int nblk, int P, const float* se1_w, const float* se1_b,
+                        const float* se3_w, const float* se3_b, int hidden, const float* w_cr,
+                        float* wp_out, float* ch_out, int B, int C, hipStream_t st) {
+    RF_CHECK_ARG(C <= 512 && hidden <= 64 && C % 2 == 0, "flca_se: C=%d hidden=%d unsupported", C, hidden);
+    ProfScope prof(st, "flca_se_fold_kernel", 0.0, 0.0);
+    flca_se_fold_kernel<<<B, 256, 0, st>>>(partial, nblk, P, se1_w, se1_b, se3_w, se3_b, hidden, w_cr, wp_out, ch_out, C);
+    return check_launch("flca_se_fold");
+}
+
+}  // namespace rf

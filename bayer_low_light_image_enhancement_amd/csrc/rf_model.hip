@@ -1,0 +1,480 @@
+// RawFormer handle: parameter registry, weight packing, workspace plan and the forward
+// schedule (RawFomer_WFB_FFAB/model.py:473-508 == FrequencyawareLumaChromaAttentionRAWFormer.py:330-370).
+// Host code only; every kernel lives in the rf_*.hip files next to this one.
+#include <string>
+#include <unordered_map>
+#include <vector>
+#include <cstring>
+#include "rf_common.h"
+
+using namespace rf;
+
+struct Param {
+    std::string name;
+    int64_t shape[4];
+    int ndim;
+    const float* ptr;
+    size_t numel() const {
+        size_t n = 1;
+        for (int i = 0; i < ndim; ++i) n *= (size_t)shape[i];
+        return n;
+    }
+};
+
+enum PackKind { PK_1x1, PK_3x3, PK_CONVT };
+struct PackItem {
+    int param;       // index of the raw weight
+    PackKind kind;
+    size_t offset;   // floats into the packed buffer
+    size_t floats;
+};
+
+struct rf_handle {
+    rf_config cfg;
+    std::vector<Param> params;
+    std::unordered_map<std::string, int> index;
+    std::vector<PackItem> packs;
+    std::unordered_map<std::string, int> pack_index;   // weight name -> packs[]
+    size_t packed_floats = 0;
+    const float* packed = nullptr;   // caller memory, valid after rf_pack_params
+};
+
+namespace {
+
+void add_param(rf_handle* h, const std::string& name, std::initializer_list<int64_t> shape) {
+    Param p;
+    p.name = name;
+    p.ndim = (int)shape.size();
+    int i = 0;
+    for (auto s : shape) p.shape[i++] = s;
+    for (; i < 4; ++i) p.shape[i] = 1;
+    p.ptr = nullptr;
+    h->index[name] = (int)h->params.size();
+    h->params.push_back(p);
+}
+
+void add_pack(rf_handle* h, const std::string& name, PackKind kind) {
+    const int pi = h->index.at(name);
+    const Param& p = h->params[pi];
+    PackItem it;
+    it.param = pi;
+    it.kind = kind;
+    it.offset = h->packed_floats;
+    if (kind == PK_1x1) it.floats = packed1x1_floats((int)p.shape[1], (int)p.shape[0]);
+    else if (kind == PK_3x3) it.floats = packed3x3_floats((int)p.shape[1], (int)p.shape[0]);
+    else it.floats = packed1x1_floats((int)p.shape[0], 4 * (int)p.shape[1]);
+    h->packed_floats += align_up(it.floats, 64);
+    h->pack_index[name] = (int)h->packs.size();
+    h->packs.push_back(it);
+}
+
+void add_stage(rf_handle* h, int i, int C, int heads) {
+    const rf_config& cfg = h->cfg;
+    const std::string pre = "conv_tran" + std::to_string(i) + ".";
+    if (cfg.variant == RF_VARIANT_FLCA) {
+        const std::string f = pre + "FLCA.";
+        const int hid = C / 8 > 8 ? C / 8 : 8;
+        add_param(h, f + "alpha", {});
+        add_param(h, f + "beta", {});
+        add_param(h, f + "gamma", {});
+        add_param(h, f + "low_attn.0.weight", {C, 1, 3, 3});
+        add_param(h, f + "high_attn.0.weight", {C, 1, 3, 3});
+        add_param(h, f + "chroma_attn.0.weight", {C, 2, 3, 3});
+        add_param(h, f + "se.1.weight", {hid, C, 1, 1});
+        add_param(h, f + "se.1.bias", {hid});
+        add_param(h, f + "se.3.weight", {C, hid, 1, 1});
+        add_param(h, f + "se.3.bias", {C});
+    } else {
+        add_param(h, pre + "conv.weight", {C, C, 3, 3});
+        add_param(h, pre + "conv.bias", {C});
+        add_pack(h, pre + "conv.weight", PK_3x3);
+    }
+    const std::string t = pre + "Transformer.";
+    const int hc = C * cfg.ffn_expansion;
+    add_param(h, t + "norm1.body.weight", {C});
+    add_param(h, t + "norm1.body.bias", {C});
+    add_param(h, t + "attn.temperature", {heads, 1, 1});
+    add_param(h, t + "attn.qkv.weight", {3 * C, C, 1, 1});
+    add_param(h, t + "attn.qkv.bias", {3 * C});
+    add_param(h, t + "attn.qkv_dwconv.weight", {3 * C, 1, 3, 3});
+    add_param(h, t + "attn.qkv_dwconv.bias", {3 * C});
+    add_param(h, t + "attn.project_out.weight", {C, C, 1, 1});
+    add_param(h, t + "attn.project_out.bias", {C});
+    add_param(h, t + "norm2.body.weight", {C});
+    add_param(h, t + "norm2.body.bias", {C});
+    add_param(h, t + "ffn.pointwise1.weight", {hc, C, 1, 1});
+    add_param(h, t + "ffn.pointwise1.bias", {hc});
+    add_param(h, t + "ffn.depthwise.weight", {hc, 1, 3, 3});
+    add_param(h, t + "ffn.depthwise.bias", {hc});
+    add_param(h, t + "ffn.pointwise2.weight", {C, hc, 1, 1});
+    add_param(h, t + "ffn.pointwise2.bias", {C});
+    add_param(h, pre + "channel_reduce.weight", {C, 2 * C, 1, 1});
+    add_param(h, pre + "channel_reduce.bias", {C});
+    add_param(h, pre + "Conv_out.weight", {C, C, 3, 3});
+    add_param(h, pre + "Conv_out.bias", {C});
+    add_pack(h, t + "attn.qkv.weight", PK_1x1);
+    add_pack(h, t + "ffn.pointwise1.weight", PK_1x1);
+    add_pack(h, t + "ffn.pointwise2.weight", PK_1x1);
+    if (cfg.variant != RF_VARIANT_FLCA) add_pack(h, pre + "channel_reduce.weight", PK_1x1);
+    add_pack(h, pre + "Conv_out.weight", PK_3x3);
+}
+
+const float* P(const rf_handle* h, const std::string& name) { return h->params[h->index.at(name)].ptr; }
+const float* PK(const rf_handle* h, const std::string& name) { return h->packed + h->packs[h->pack_index.at(name)].offset; }
+
+// ---- workspace plan ---------------------------------------------------------------------
+struct Plan {
+    size_t total = 0;
+    size_t gscratch, guide[4], skip[3], tA, tB, tU, bufA, bufB, x1, trans, xs, cr;
+    size_t gram_partial, wfold_attn, wfold_cr, flca_partial, ch;
+};
+
+size_t take(Plan& p, size_t floats) {
+    const size_t off = p.total;
+    p.total += align_up(floats, 64);   // 256-byte granules keep every buffer 16-byte aligned
+    return off;
+}
+
+int make_plan(const rf_handle* h, int B, int H, int W, Plan& p) {
+    const rf_config& c = h->cfg;
+    const size_t U0 = (size_t)B * c.dim * H * W;   // floats of a level-0 activation
+    p.gscratch = take(p, guidance_scratch_floats(B, H, W));
+    for (int l = 0; l < 4; ++l) p.guide[l] = take(p, (size_t)B * 4 * (H >> l) * (W >> l));
+    for (int l = 0; l < 3; ++l) p.skip[l] = take(p, U0 >> l);
+    p.tA = take(p, U0);
+    p.tB = take(p, U0);
+    p.tU = take(p, U0);
+    p.bufA = take(p, 3 * U0);
+    p.bufB = take(p, 3 * U0);
+    p.x1 = take(p, U0);
+    p.trans = take(p, U0);
+    p.xs = take(p, U0);
+    p.cr = take(p, U0);
+    size_t gp = 0, wa = 0, wc = 0, fp = 0;
+    for (int l = 0; l < 4; ++l) {
+        const int C = c.dim << l, Pl = (H >> l) * (W >> l);
+        int ns, sl;
+        size_t pf;
+        const int rc = gram_plan(B, C, c.heads[l], Pl, &ns, &sl, &pf);
+        if (rc) return rc;
+        if (pf > gp) gp = pf;
+        const size_t a = (size_t)B * packed1x1_floats(C, C), cr = (size_t)B * packed1x1_floats(2 * C, C);
+        if (a > wa) wa = a;
+        if (cr > wc) wc = cr;
+        const size_t f = (size_t)B * flca_nblk(H >> l, W >> l) * C;
+        if (f > fp) fp = f;
+    }
+    p.gram_partial = take(p, gp);
+    p.wfold_attn = take(p, wa);
+    p.wfold_cr = take(p, wc);
+    p.flca_partial = take(p, fp);
+    p.ch = take(p, (size_t)B * (c.dim << 3));
+    return RF_OK;
+}
+
+#define RF_TRY(expr)          \
+    do {                      \
+        const int rc_ = (expr); \
+        if (rc_) return rc_;  \
+    } while (0)
+
+// one Conv_Transformer stage
+int run_stage(const rf_handle* h, int i, int lvl, const float* in, float* out, float* ws, const Plan& p,
+              int B, int H, int W, hipStream_t st) {
+    const rf_config& cfg = h->cfg;
+    const int C = cfg.dim << lvl, hh = H >> lvl, ww = W >> lvl, Pn = hh * ww, heads = cfg.heads[lvl];
+    const int hc = C * cfg.ffn_expansion;
+    const std::string pre = "conv_tran" + std::to_string(i) + ".", t = pre + "Transformer.";
+    float* bufA = ws + p.bufA;
+    float* bufB = ws + p.bufB;
+    float* x1 = ws + p.x1;
+    float* trans = ws + p.trans;
+    float* xs = ws + p.xs;
+    float* crb = ws + p.cr;
+
+    // x + attn(LN1(x)) ---------------------------------------------------------------------
+    Conv1x1Args q{};
+    q.x1 = in; q.C1 = C; q.x1_bstride = (int64_t)C * Pn;
+    q.wp = PK(h, t + "attn.qkv.weight"); q.bias = P(h, t + "attn.qkv.bias");
+    q.ln_w = P(h, t + "norm1.body.weight"); q.ln_b = P(h, t + "norm1.body.bias"); q.ln_eps = 1e-5f;
+    q.out = bufA; q.out_bstride = (int64_t)3 * C * Pn; q.Cout = 3 * C; q.B = B; q.P = Pn; q.w = ww;
+    RF_TRY(launch_conv1x1(q, st));
+
+    DwConvArgs d{};
+    d.x = bufA; d.x_bstride = (int64_t)3 * C * Pn; d.out = bufB; d.out_bstride = (int64_t)3 * C * Pn;
+    d.w = P(h, t + "attn.qkv_dwconv.weight"); d.bias = P(h, t + "attn.qkv_dwconv.bias");
+    d.B = B; d.C = 3 * C; d.h = hh; d.w_ = ww; d.gelu = 0;
+    RF_TRY(launch_dwconv3x3(d, st));
+
+    GramArgs g{};
+    g.q = bufB; g.k = bufB + (size_t)C * Pn; g.bstride = (int64_t)3 * C * Pn;
+    g.B = B; g.C = C; g.heads = heads; g.P = Pn; g.partial = ws + p.gram_partial;
+    size_t pf;
+    RF_TRY(gram_plan(B, C, heads, Pn, &g.nslab, &g.slab, &pf));
+    RF_TRY(launch_gram(g, st));
+    RF_TRY(launch_attn_fold(g.partial, g.nslab, P(h, t + "attn.temperature"), P(h, t + "attn.project_out.weight"),
+                            ws + p.wfold_attn, B, C, heads, st));
+
+    Conv1x1Args av{};
+    av.x1 = bufB + (size_t)2 * C * Pn; av.C1 = C; av.x1_bstride = (int64_t)3 * C * Pn;
+    av.wp = ws + p.wfold_attn; av.wp_bstride = (int64_t)packed1x1_floats(C, C);
+    av.bias = P(h, t + "attn.project_out.bias");
+    av.res = in; av.res_bstride = (int64_t)C * Pn;
+    av.out = x1; av.out_bstride = (int64_t)C * Pn; av.Cout = C; av.B = B; av.P = Pn; av.w = ww;
+    RF_TRY(launch_conv1x1(av, st));
+
+    // x + ffn(LN2(x)) ----------------------------------------------------------------------
+    Conv1x1Args f1{};
+    f1.x1 = x1; f1.C1 = C; f1.x1_bstride = (int64_t)C * Pn;
+    f1.wp = PK(h, t + "ffn.pointwise1.weight"); f1.bias = P(h, t + "ffn.pointwise1.bias");
+    f1.ln_w = P(h, t + "norm2.body.weight"); f1.ln_b = P(h, t + "norm2.body.bias"); f1.ln_eps = 1e-5f;
+    f1.out = bufA; f1.out_bstride = (int64_t)hc * Pn; f1.Cout = hc; f1.B = B; f1.P = Pn; f1.w = ww;
+    RF_TRY(launch_conv1x1(f1, st));
+
+    DwConvArgs d2{};
+    d2.x = bufA; d2.x_bstride = (int64_t)hc * Pn; d2.out = bufB; d2.out_bstride = (int64_t)hc * Pn;
+    d2.w = P(h, t + "ffn.depthwise.weight"); d2.bias = P(h, t + "ffn.depthwise.bias");
+    d2.B = B; d2.C = hc; d2.h = hh; d2.w_ = ww; d2.gelu = 1;
+    RF_TRY(launch_dwconv3x3(d2, st));
+
+    Conv1x1Args f2{};
+    f2.x1 = bufB; f2.C1 = hc; f2.x1_bstride = (int64_t)hc * Pn;
+    f2.wp = PK(h, t + "ffn.pointwise2.weight"); f2.bias = P(h, t + "ffn.pointwise2.bias");
+    f2.res = x1; f2.res_bstride = (int64_t)C * Pn;
+    f2.out = trans; f2.out_bstride = (int64_t)C * Pn; f2.Cout = C; f2.B = B; f2.P = Pn; f2.w = ww;
+    RF_TRY(launch_conv1x1(f2, st));
+
+    // branch, cat, channel_reduce -------------------------------------------------------------
+    Conv1x1Args r{};
+    r.x1 = xs; r.C1 = C; r.x1_bstride = (int64_t)C * Pn;
+    r.x2 = trans; r.C2 = C; r.x2_bstride = (int64_t)C * Pn;
+    r.bias = P(h, pre + "channel_reduce.bias");
+    r.out = crb; r.out_bstride = (int64_t)C * Pn; r.Cout = C; r.B = B; r.P = Pn; r.w = ww;
+    if (cfg.variant == RF_VARIANT_FLCA) {
+        const std::string f = pre + "FLCA.";
+        FlcaSpatialArgs s{};
+        s.feat = in; s.xs = xs; s.guide = ws + p.guide[lvl];
+        s.w_low = P(h, f + "low_attn.0.weight"); s.w_high = P(h, f + "high_attn.0.weight"); s.w_chr = P(h, f + "chroma_attn.0.weight");
+        s.alpha = P(h, f + "alpha"); s.beta = P(h, f + "beta"); s.gamma = P(h, f + "gamma");
+        s.partial = ws + p.flca_partial; s.B = B; s.C = C; s.h = hh; s.w = ww; s.nblk = flca_nblk(hh, ww);
+        RF_TRY(launch_flca_spatial(s, st));
+        const int hid = C / 8 > 8 ? C / 8 : 8;
+        RF_TRY(launch_flca_se_fold(s.partial, s.nblk, Pn, P(h, f + "se.1.weight"), P(h, f + "se.1.bias"),
+                                   P(h, f + "se.3.weight"), P(h, f + "se.3.bias"), hid, P(h, pre + "channel_reduce.weight"),
+                                   ws + p.wfold_cr, ws + p.ch, B, C, st));
+        r.wp = ws + p.wfold_cr; r.wp_bstride = (int64_t)packed1x1_floats(2 * C, C);
+    } else {
+        Conv3x3Args cb{};
+        cb.x = in; cb.x_bstride = (int64_t)C * Pn; cb.wp = PK(h, pre + "conv.weight"); cb.bias = P(h, pre + "conv.bias");
+        cb.out = xs; cb.out_bstride = (int64_t)C * Pn; cb.B = B; cb.Cin = C; cb.Cout = C; cb.h = hh; cb.w = ww;
+        cb.act = cfg.branch_lrelu ? 1 : 0;
+        RF_TRY(launch_conv3x3(cb, st));
+        r.wp = PK(h, pre + "channel_reduce.weight");
+    }
+    RF_TRY(launch_conv1x1(r, st));
+
+    Conv3x3Args co{};
+    co.x = crb; co.x_bstride = (int64_t)C * Pn; co.wp = PK(h, pre + "Conv_out.weight"); co.bias = P(h, pre + "Conv_out.bias");
+    co.out = out; co.out_bstride = (int64_t)C * Pn; co.B = B; co.Cin = C; co.Cout = C; co.h = hh; co.w = ww; co.act = 1;
+    RF_TRY(launch_conv3x3(co, st));
+    return RF_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int rf_create(const rf_config* cfg, rf_handle** out) {
+    RF_CHECK_ARG(cfg && out, "rf_create: null argument");
+    RF_CHECK_ARG(cfg->dim > 0 && cfg->dim % 8 == 0, "rf_create: dim=%d must be a positive multiple of 8", cfg->dim);
+    RF_CHECK_ARG(cfg->inp_channels == 1, "rf_create: inp_channels=%d (only the 1-channel Bayer mosaic is supported)", cfg->inp_channels);
+    RF_CHECK_ARG(cfg->out_channels > 0 && cfg->ffn_expansion > 0, "rf_create: bad out_channels / ffn_expansion");
+    RF_CHECK_ARG(cfg->variant == RF_VARIANT_FLCA || cfg->variant == RF_VARIANT_PLAIN, "rf_create: unknown variant %d", cfg->variant);
+    for (int l = 0; l < 4; ++l) {
+        const int C = cfg->dim << l;
+        RF_CHECK_ARG(cfg->heads[l] > 0 && C % cfg->heads[l] == 0 && C / cfg->heads[l] <= 64,
+                     "rf_create: heads[%d]=%d incompatible with %d channels (head size must divide and be <= 64)", l, cfg->heads[l], C);
+    }
+    rf_handle* h = new rf_handle();
+    h->cfg = *cfg;
+    const int d = cfg->dim;
+    add_param(h, "embedding.weight", {d, 4 * cfg->inp_channels, 3, 3});
+    add_param(h, "embedding.bias", {d});
+    add_pack(h, "embedding.weight", PK_3x3);
+    for (int i = 1; i <= 3; ++i) {
+        const int C = d << (i - 1);
+        add_stage(h, i, C, cfg->heads[i - 1]);
+        const std::string n = "down" + std::to_string(i) + ".body.0.weight";
+        add_param(h, n, {C / 2, C, 3, 3});
+        add_pack(h, n, PK_3x3);
+    }
+    add_stage(h, 4, d * 8, cfg->heads[3]);
+    for (int i = 1; i <= 3; ++i) {
+        const int lvl = 3 - i, C = d << lvl;
+        const std::string u = "up" + std::to_string(i), r = "channel_reduce" + std::to_string(i);
+        add_param(h, u + ".weight", {2 * C, C, 2, 2});
+        add_param(h, u + ".bias", {C});
+        add_param(h, r + ".weight", {C, 2 * C, 1, 1});
+        add_param(h, r + ".bias", {C});
+        add_pack(h, u + ".weight", PK_CONVT);
+        add_pack(h, r + ".weight", PK_1x1);
+        add_stage(h, 4 + i, C, cfg->heads[lvl]);
+    }
+    add_param(h, "conv_out.weight", {4 * cfg->out_channels, d, 3, 3});
+    add_param(h, "conv_out.bias", {4 * cfg->out_channels});
+    add_pack(h, "conv_out.weight", PK_3x3);
+    *out = h;
+    return RF_OK;
+}
+
+void rf_destroy(rf_handle* h) { delete h; }
+
+int rf_param_count(const rf_handle* h) { return h ? (int)h->params.size() : RF_E_INVALID; }
+
+int rf_param_info(const rf_handle* h, int index, const char** name, int64_t shape[4], int* ndim) {
+    RF_CHECK_ARG(h && index >= 0 && index < (int)h->params.size(), "rf_param_info: index %d out of range", index);
+    const Param& p = h->params[index];
+    if (name) *name = p.name.c_str();
+    if (shape) std::memcpy(shape, p.shape, sizeof(p.shape));
+    if (ndim) *ndim = p.ndim;
+    return RF_OK;
+}
+
+int rf_set_param(rf_handle* h, const char* name, const float* dev_ptr, const int64_t* shape, int ndim) {
+    RF_CHECK_ARG(h && name && dev_ptr, "rf_set_param: null argument");
+    auto it = h->index.find(name);
+    if (it == h->index.end()) {
+        set_error("rf_set_param: unexpected key '%s'", name);
+        return RF_E_MISSING;
+    }
+    Param& p = h->params[it->second];
+    size_t n = 1;
+    for (int i = 0; i < ndim; ++i) n *= (size_t)shape[i];
+    bool same = n == p.numel();
+    // accept [heads,1,1] vs [1,heads,1,1] style differences, reject anything that changes sizes
+    if (same && ndim == p.ndim)
+        for (int i = 0; i < ndim; ++i) same = same && shape[i] == p.shape[i];
+    else if (same)
+        same = p.ndim <= 1 || p.name.find("temperature") != std::string::npos;
+    RF_CHECK_ARG(same, "rf_set_param: size mismatch for %s: got %zu elements in %d dims, expected %zu", name, n, ndim, p.numel());
+    RF_CHECK_ARG((reinterpret_cast<uintptr_t>(dev_ptr) & 3) == 0, "rf_set_param: %s is not 4-byte aligned", name);
+    p.ptr = dev_ptr;
+    h->packed = nullptr;
+    return RF_OK;
+}
+
+int rf_packed_bytes(const rf_handle* h, size_t* bytes) {
+    RF_CHECK_ARG(h && bytes, "rf_packed_bytes: null argument");
+    *bytes = h->packed_floats * sizeof(float);
+    return RF_OK;
+}
+
+int rf_pack_params(rf_handle* h, void* packed_dev, size_t bytes, void* stream) {
+    RF_CHECK_ARG(h && packed_dev, "rf_pack_params: null argument");
+    RF_CHECK_ARG(aligned16(packed_dev), "rf_pack_params: buffer must be 16-byte aligned");
+    if (bytes < h->packed_floats * sizeof(float)) {
+        set_error("rf_pack_params: buffer of %zu bytes, need %zu", bytes, h->packed_floats * sizeof(float));
+        return RF_E_NOMEM;
+    }
+    for (const Param& p : h->params)
+        if (!p.ptr) {
+            set_error("rf_pack_params: missing key '%s'", p.name.c_str());
+            return RF_E_MISSING;
+        }
+    hipStream_t st = (hipStream_t)stream;
+    float* base = (float*)packed_dev;
+    for (const PackItem& it : h->packs) {
+        const Param& p = h->params[it.param];
+        int rc;
+        if (it.kind == PK_1x1) rc = pack_1x1(p.ptr, base + it.offset, (int)p.shape[0], (int)p.shape[1], p.shape[1], 1, st);
+        else if (it.kind == PK_3x3) rc = pack_3x3(p.ptr, base + it.offset, (int)p.shape[0], (int)p.shape[1], st);
+        else rc = pack_convT(p.ptr, base + it.offset, (int)p.shape[0], (int)p.shape[1], st);
+        if (rc) return rc;
+    }
+    h->packed = base;
+    return RF_OK;
+}
+
+int rf_workspace_bytes(const rf_handle* h, int B, int H, int W, size_t* bytes) {
+    RF_CHECK_ARG(h && bytes, "rf_workspace_bytes: null argument");
+    RF_CHECK_ARG(B > 0 && H > 0 && W > 0 && H % 8 == 0 && W % 8 == 0, "packed size %dx%d must be positive multiples of 8 (mosaic divisible by 16)", H, W);
+    Plan p;
+    RF_TRY(make_plan(h, B, H, W, p));
+    *bytes = p.total * sizeof(float);
+    return RF_OK;
+}
+
+int rf_forward(rf_handle* h, const float* in, float* out, void* workspace, size_t workspace_bytes,
+               int B, int H, int W, int packed_input, void* stream) {
+    RF_CHECK_ARG(h && in && out && workspace, "rf_forward: null argument");
+    RF_CHECK_ARG(B > 0 && B <= 65535 && H > 0 && W > 0 && H % 8 == 0 && W % 8 == 0,
+                 "rf_forward: packed size %dx%d must be positive multiples of 8 (mosaic divisible by 16)", H, W);
+    RF_CHECK_ARG((size_t)H * W < (1u << 30), "rf_forward: frame too large");
+    if (!h->packed) {
+        set_error("rf_forward: parameters not packed (call rf_pack_params after rf_set_param)");
+        return RF_E_MISSING;
+    }
+    RF_CHECK_ARG(aligned16(workspace) && aligned16(in) && aligned16(out), "rf_forward: buffers must be 16-byte aligned");
+    Plan p;
+    RF_TRY(make_plan(h, B, H, W, p));
+    if (workspace_bytes < p.total * sizeof(float)) {
+        set_error("rf_forward: workspace of %zu bytes, need %zu", workspace_bytes, p.total * sizeof(float));
+        return RF_E_NOMEM;
+    }
+    const rf_config& cfg = h->cfg;
+    hipStream_t st = (hipStream_t)stream;
+    float* ws = (float*)workspace;
+    const int d = cfg.dim;
+    const int mosaic = packed_input ? 0 : 1;
+
+    if (cfg.variant == RF_VARIANT_FLCA) {
+        RF_TRY(launch_guidance_base(in, mosaic, cfg.clamp_io, ws + p.gscratch, B, H, W, st));
+        for (int l = 0; l < 4; ++l)
+            RF_TRY(launch_guidance_level(ws + p.gscratch, ws + p.guide[l], B, H, W, H >> l, W >> l, st));
+    }
+    // embedding (reads the mosaic through the Bayer pack)
+    Conv3x3Args e{};
+    e.x = in; e.x_bstride = (int64_t)4 * H * W; e.wp = PK(h, "embedding.weight"); e.bias = P(h, "embedding.bias");
+    e.out = ws + p.tA; e.out_bstride = (int64_t)d * H * W; e.B = B; e.Cin = 4; e.Cout = d; e.h = H; e.w = W;
+    e.unshuffle_in = mosaic; e.clamp_in = cfg.clamp_io;
+    RF_TRY(launch_conv3x3(e, st));
+
+    // encoder
+    float* skip[3] = {ws + p.skip[0], ws + p.skip[1], ws + p.skip[2]};
+    for (int i = 1; i <= 3; ++i) {
+        const int lvl = i - 1, C = d << lvl, hh = H >> lvl, ww = W >> lvl;
+        RF_TRY(run_stage(h, i, lvl, ws + p.tA, skip[lvl], ws, p, B, H, W, st));
+        Conv3x3Args dn{};
+        dn.x = skip[lvl]; dn.x_bstride = (int64_t)C * hh * ww; dn.wp = PK(h, "down" + std::to_string(i) + ".body.0.weight");
+        dn.out = ws + p.tA; dn.out_bstride = (int64_t)2 * C * (hh / 2) * (ww / 2);
+        dn.B = B; dn.Cin = C; dn.Cout = C / 2; dn.h = hh; dn.w = ww; dn.store = 1;
+        RF_TRY(launch_conv3x3(dn, st));
+    }
+    RF_TRY(run_stage(h, 4, 3, ws + p.tA, ws + p.tB, ws, p, B, H, W, st));
+    // decoder
+    for (int i = 1; i <= 3; ++i) {
+        const int lvl = 3 - i, C = d << lvl, hh = H >> lvl, ww = W >> lvl, Pn = hh * ww;
+        const std::string u = "up" + std::to_string(i), r = "channel_reduce" + std::to_string(i);
+        Conv1x1Args up{};
+        up.x1 = ws + p.tB; up.C1 = 2 * C; up.x1_bstride = (int64_t)2 * C * (Pn / 4);
+        up.wp = PK(h, u + ".weight"); up.bias = P(h, u + ".bias");
+        up.out = ws + p.tU; up.out_bstride = (int64_t)C * Pn; up.Cout = 4 * C; up.B = B; up.P = Pn / 4; up.w = ww / 2; up.mode = 1;
+        RF_TRY(launch_conv1x1(up, st));
+        Conv1x1Args cr{};
+        cr.x1 = ws + p.tU; cr.C1 = C; cr.x1_bstride = (int64_t)C * Pn;
+        cr.x2 = skip[lvl]; cr.C2 = C; cr.x2_bstride = (int64_t)C * Pn;
+        cr.wp = PK(h, r + ".weight"); cr.bias = P(h, r + ".bias");
+        cr.out = ws + p.tA; cr.out_bstride = (int64_t)C * Pn; cr.Cout = C; cr.B = B; cr.P = Pn; cr.w = ww;
+        RF_TRY(launch_conv1x1(cr, st));
+        RF_TRY(run_stage(h, 4 + i, lvl, ws + p.tA, ws + p.tB, ws, p, B, H, W, st));
+    }
+    // conv_out + LeakyReLU + PixelShuffle (+ clamp)
+    Conv3x3Args o{};
+    o.x = ws + p.tB; o.x_bstride = (int64_t)d * H * W; o.wp = PK(h, "conv_out.weight"); o.bias = P(h, "conv_out.bias");
+    o.out = out; o.out_bstride = (int64_t)cfg.out_channels * 4 * H * W;
+    o.B = B; o.Cin = d; o.Cout = 4 * cfg.out_channels; o.h = H; o.w = W; o.act = 1; o.store = 2; o.clamp_out = cfg.clamp_io;
+    RF_TRY(launch_conv3x3(o, st));
+    return RF_OK;
+}
+
+}  // extern "C"

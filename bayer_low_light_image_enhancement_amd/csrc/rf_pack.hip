@@ -1,0 +1,54 @@
+// Weight repacking into v_mfma_f32_16x16x4_f32 A-operand order (layouts: rf_common.h).
+// Runs once per parameter load (rf_pack_params), not per forward.
+#include "rf_common.h"
+
+namespace rf {
+
+__global__ void __launch_bounds__(256) pack_1x1_kernel(const float* __restrict__ w, float* __restrict__ packed,
+                                                       int Cout, int K, int64_t row_stride, int64_t col_stride) {
+    const int NT = (Cout + 15) >> 4, NS = (K + 3) >> 2;
+    const size_t total = (size_t)NT * NS * 64;
+    for (size_t idx = blockIdx.x * 256ull + threadIdx.x; idx < total; idx += (size_t)gridDim.x * 256) {
+        const int l = (int)(idx & 63);
+        const int t = (int)((idx >> 6) % NT);
+        const int s = (int)((idx >> 6) / NT);
+        const int co = 16 * t + (l & 15), k = 4 * s + (l >> 4);
+        packed[idx] = (co < Cout && k < K) ? w[co * row_stride + k * col_stride] : 0.f;
+    }
+}
+
+int pack_1x1(const float* w, float* packed, int Cout, int K, int64_t row_stride, int64_t col_stride, hipStream_t st) {
+    const size_t total = packed1x1_floats(K, Cout);
+    int g = (int)((total + 255) / 256);
+    if (g > 4096) g = 4096;
+    pack_1x1_kernel<<<g, 256, 0, st>>>(w, packed, Cout, K, row_stride, col_stride);
+    return check_launch("pack_1x1");
+}
+
+// nn.ConvTranspose2d weight [Cin][Cout][2][2]: GEMM row 4*o + 2*i + j, column k
+int pack_convT(const float* w, float* packed, int Cin, int Cout, hipStream_t st) {
+    return pack_1x1(w, packed, 4 * Cout, Cin, 1, (int64_t)4 * Cout, st);
+}
+
+__global__ void __launch_bounds__(256) pack_3x3_kernel(const float* __restrict__ w, float* __restrict__ packed, int Cout, int Cin) {
+    const int NT = (Cout + 15) >> 4, NS = ((Cin + 7) >> 3) * 2;
+    const size_t total = (size_t)NS * 9 * NT * 64;
+    for (size_t idx = blockIdx.x * 256ull + threadIdx.x; idx < total; idx += (size_t)gridDim.x * 256) {
+        const int l = (int)(idx & 63);
+        const int t = (int)((idx >> 6) % NT);
+        const int tap = (int)(((idx >> 6) / NT) % 9);
+        const int s = (int)((idx >> 6) / ((size_t)NT * 9));
+        const int co = 16 * t + (l & 15), ci = 4 * s + (l >> 4);
+        packed[idx] = (co < Cout && ci < Cin) ? w[((size_t)co * Cin + ci) * 9 + tap] : 0.f;
+    }
+}
+
+int pack_3x3(const float* w, float* packed, int Cout, int Cin, hipStream_t st) {
+    const size_t total = packed3x3_floats(Cin, Cout);
+    int g = (int)((total + 255) / 256);
+    if (g > 4096) g = 4096;
+    pack_3x3_kernel<<<g, 256, 0, st>>>(w, packed, Cout, Cin);
+    return check_launch("pack_3x3");
+}
+
+}  // namespace rf

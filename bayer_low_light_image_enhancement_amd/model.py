@@ -1,0 +1,309 @@
+"""Drop-in ``RawFormer(nn.Module)`` whose ``forward`` runs on hand-written gfx950 kernels.
+
+Interface kept from the reference:
+
+* constructor ``RawFormer(inp_channels=1, out_channels=3, dim=48, num_heads=[8,8,8,8],
+  ffn_expansion_factor=2)`` -- RawFomer_WFB_FFAB/model.py:448,
+  FrequencyawareLumaChromaAttentionRAWFormer.py:296 (root ``model.py:111`` spells the same
+  arguments ``in_ch, out_ch, dim, heads, ffn_exp``; those keywords are accepted too);
+* ``state_dict()`` / ``load_state_dict(strict=True)`` with the reference's key names (the
+  ``module.`` prefix left by ``nn.DataParallel`` is stripped, test.py:90);
+* ``forward(x[B,1,2H,2W]) -> [B,3,2H,2W]`` float32, input not modified (test.py:116).
+
+``variant='flca'`` is the wiring of FrequencyawareLumaChromaAttentionRAWFormer.py:284-370
+(the only whole model of the reference that runs); ``variant='plain'`` replaces the FLCA
+branch by the 3x3 conv branch of RawFomer_WFB_FFAB/model.py:393-412 (``branch_lrelu=True``)
+or model.py:94-108 (``False``) and, with ``clamp_io=True``, adds the I/O clamps of
+RawFomer_WFB_FFAB/model.py:475,508.
+
+The module owns ordinary ``nn.Parameter`` objects; the HIP library borrows their device
+pointers.  There is no PyTorch fallback: on a CPU tensor ``forward`` raises.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import math
+import threading
+from typing import Dict, List, Optional, Sequence
+
+import torch
+import torch.nn as nn
+
+from . import _lib
+
+_ROOT_STAGE_ALIASES = (
+    ("transformer.norm1.norm.", "Transformer.norm1.body."),
+    ("transformer.norm2.norm.", "Transformer.norm2.body."),
+    ("transformer.attn.scale", "Transformer.attn.temperature"),
+    ("transformer.attn.qkv.0.", "Transformer.attn.qkv."),
+    ("transformer.attn.qkv.1.", "Transformer.attn.qkv_dwconv."),
+    ("transformer.attn.proj.", "Transformer.attn.project_out."),
+    ("transformer.ffn.net.0.", "Transformer.ffn.pointwise1."),
+    ("transformer.ffn.net.1.", "Transformer.ffn.depthwise."),
+    ("transformer.ffn.net.3.", "Transformer.ffn.pointwise2."),
+    ("reduce.", "channel_reduce."),
+    ("out.0.", "Conv_out."),
+    ("conv.", "conv."),
+)
+
+
+def canonical_key(key: str) -> str:
+    """Map a checkpoint key to this module's naming: strips ``module.`` (test.py:90) and
+    translates the root ``model.py`` layout to the
+    RawFomer_WFB_FFAB / FrequencyawareLumaChroma layout."""
+    if key.startswith("module."):
+        key = key[len("module."):]
+    head, _, rest = key.partition(".")
+    stage = None
+    if head == "embed":
+        return "embedding." + rest
+    if head == "output" and rest.startswith("0."):
+        return "conv_out." + rest[2:]
+    if head == "encoder":
+        i, _, rest = rest.partition(".")
+        stage = f"conv_tran{int(i) + 1}."
+    elif head == "bottleneck":
+        stage = "conv_tran4."
+    elif head == "decoder":
+        i, _, rest = rest.partition(".")
+        stage = f"conv_tran{int(i) + 5}."
+    elif head == "downsamples":
+        i, _, rest = rest.partition(".")
+        return f"down{int(i) + 1}.body.0." + rest[len("net.0."):] if rest.startswith("net.0.") else key
+    elif head == "upsamples":
+        i, _, rest = rest.partition(".")
+        return f"up{int(i) + 1}." + rest
+    if stage is None:
+        return key
+    for a, b in _ROOT_STAGE_ALIASES:
+        if rest.startswith(a):
+            return stage + b + rest[len(a):]
+    return stage + rest
+
+
+class _Node(nn.Module):
+    """Name-only container so parameters get the reference's dotted state_dict keys."""
+
+    def forward(self, *a, **k):  # pragma: no cover - never called
+        raise RuntimeError("container module; call RawFormer.forward")
+
+
+class _DeviceState:
+    def __init__(self):
+        self.handle = C.c_void_p()
+        self.signature = None
+        self.packed: Optional[torch.Tensor] = None
+        self.workspace: Optional[torch.Tensor] = None
+
+
+class RawFormer(nn.Module):
+    def __init__(self, inp_channels: int = 1, out_channels: int = 3, dim: int = 48,
+                 num_heads: Sequence[int] = (8, 8, 8, 8), ffn_expansion_factor: int = 2, *,
+                 variant: str = "flca", branch_lrelu: bool = True, clamp_io: bool = False,
+                 in_ch: Optional[int] = None, out_ch: Optional[int] = None,
+                 heads: Optional[Sequence[int]] = None, ffn_exp: Optional[int] = None):
+        super().__init__()
+        inp_channels = in_ch if in_ch is not None else inp_channels
+        out_channels = out_ch if out_ch is not None else out_channels
+        num_heads = list(heads if heads is not None else num_heads)
+        ffn_expansion_factor = ffn_exp if ffn_exp is not None else ffn_expansion_factor
+        if variant not in ("flca", "plain"):
+            raise ValueError(f"variant must be 'flca' or 'plain', got {variant!r}")
+        if len(num_heads) != 4:
+            raise ValueError("num_heads must have 4 entries")
+        self.dim, self.inp_channels, self.out_channels = int(dim), int(inp_channels), int(out_channels)
+        self.num_heads, self.ffn_expansion_factor = [int(h) for h in num_heads], int(ffn_expansion_factor)
+        self.variant, self.branch_lrelu, self.clamp_io = variant, bool(branch_lrelu), bool(clamp_io)
+
+        cfg = self._config()
+        lib = _lib.load()
+        probe = C.c_void_p()
+        _lib.check(lib.rf_create(C.byref(cfg), C.byref(probe)), "rf_create")
+        try:
+            self._param_names: List[str] = []
+            name, shape, ndim = C.c_char_p(), (C.c_int64 * 4)(), C.c_int()
+            for i in range(lib.rf_param_count(probe)):
+                _lib.check(lib.rf_param_info(probe, i, C.byref(name), C.byref(shape), C.byref(ndim)), "rf_param_info")
+                key = name.value.decode()
+                self._param_names.append(key)
+                self._register(key, nn.Parameter(torch.empty(tuple(shape[: ndim.value]), dtype=torch.float32)))
+        finally:
+            lib.rf_destroy(probe)
+        if variant == "flca":
+            # fixed buffers the reference keeps in its state_dict (values are constants in the kernels)
+            for k, v in (("r_w", 0.299), ("g_w", 0.587), ("b_w", 0.114)):
+                self._register_buffer("luma_chroma." + k, torch.tensor(v, dtype=torch.float32))
+            hv = torch.tensor([1.0, 1.0]) / math.sqrt(2.0)
+            gv = torch.tensor([1.0, -1.0]) / math.sqrt(2.0)
+            filt = torch.stack([torch.outer(hv, hv), torch.outer(hv, gv), torch.outer(gv, hv), torch.outer(gv, gv)]).unsqueeze(1)
+            for i in range(1, 8):
+                self._register_buffer(f"conv_tran{i}.FLCA.dwt.filt", filt.clone())
+        self.reset_parameters()
+        self._rt: Dict[int, _DeviceState] = {}
+        self._rt_lock = threading.Lock()
+        self._rt_owner = id(self)   # nn.DataParallel replicas share __dict__ entries; only the owner frees handles
+
+    # ------------------------------------------------------------------ construction helpers
+    def _config(self) -> _lib.RfConfig:
+        return _lib.RfConfig(self.dim, (C.c_int32 * 4)(*self.num_heads), self.inp_channels, self.out_channels,
+                             self.ffn_expansion_factor,
+                             _lib.RF_VARIANT_FLCA if self.variant == "flca" else _lib.RF_VARIANT_PLAIN,
+                             int(self.branch_lrelu), int(self.clamp_io))
+
+    def _node(self, path: List[str]) -> nn.Module:
+        mod: nn.Module = self
+        for part in path:
+            if part not in mod._modules:
+                mod.add_module(part, _Node())
+            mod = mod._modules[part]
+        return mod
+
+    def _register(self, key: str, p: nn.Parameter) -> None:
+        *path, leaf = key.split(".")
+        self._node(path).register_parameter(leaf, p)
+
+    def _register_buffer(self, key: str, t: torch.Tensor) -> None:
+        *path, leaf = key.split(".")
+        self._node(path).register_buffer(leaf, t)
+
+    @torch.no_grad()
+    def reset_parameters(self) -> None:
+        """PyTorch's default initialisers (what the reference's ``__init__`` leaves behind)."""
+        params = dict(self.named_parameters())
+        for key, p in params.items():
+            leaf = key.rsplit(".", 1)[-1]
+            if leaf in ("alpha", "beta", "gamma", "temperature"):
+                p.fill_(1.0)
+            elif p.dim() == 1:
+                if leaf == "weight":
+                    p.fill_(1.0)                      # LayerNorm scale
+                elif "norm" in key:
+                    p.zero_()                          # LayerNorm shift
+                else:                                  # conv bias: U(-1/sqrt(fan_in), 1/sqrt(fan_in))
+                    w = params[key[: -len("bias")] + "weight"]
+                    fan_in = w[0].numel()              # also what torch uses for ConvTranspose2d [Cin,Cout,2,2]
+                    bound = 1.0 / math.sqrt(max(fan_in, 1))
+                    p.uniform_(-bound, bound)
+            else:
+                nn.init.kaiming_uniform_(p, a=math.sqrt(5))
+
+    # ------------------------------------------------------------------ state_dict compatibility
+    def _load_from_state_dict(self, state_dict, prefix, *args, **kwargs):
+        if prefix == "":
+            for k in list(state_dict.keys()):
+                ck = canonical_key(k)
+                if ck != k:
+                    state_dict[ck] = state_dict.pop(k)
+            # temperature may arrive as [1,heads,1,1] (root model.py `scale`)
+            for k, v in list(state_dict.items()):
+                if k.endswith("attn.temperature") and v.dim() == 4:
+                    state_dict[k] = v.reshape(v.shape[1], 1, 1)
+        super()._load_from_state_dict(state_dict, prefix, *args, **kwargs)
+
+    # ------------------------------------------------------------------ runtime
+    def _state_for(self, device: torch.device) -> _DeviceState:
+        idx = device.index if device.index is not None else torch.cuda.current_device()
+        with self._rt_lock:
+            st = self._rt.get(idx)
+            if st is None:
+                st = _DeviceState()
+                cfg = self._config()
+                _lib.check(_lib.load().rf_create(C.byref(cfg), C.byref(st.handle)), "rf_create")
+                self._rt[idx] = st
+        return st
+
+    def _sync_params(self, st: _DeviceState, device: torch.device) -> None:
+        params = dict(self.named_parameters())
+        sig = tuple((p.data_ptr(), p._version) for p in (params[k] for k in self._param_names))
+        if sig == st.signature:
+            return
+        lib = _lib.load()
+        for k in self._param_names:
+            p = params[k]
+            if p.device != device:
+                raise RuntimeError(f"parameter {k} is on {p.device} but the input is on {device}; call model.to(device)")
+            if p.dtype != torch.float32 or not p.is_contiguous():
+                raise RuntimeError(f"parameter {k} must be contiguous float32")
+            shape = (C.c_int64 * max(p.dim(), 1))(*p.shape)
+            _lib.check(lib.rf_set_param(st.handle, k.encode(), C.c_void_p(p.data_ptr()), shape, p.dim()), "rf_set_param")
+        sz = C.c_size_t()
+        _lib.check(lib.rf_packed_bytes(st.handle, C.byref(sz)), "rf_packed_bytes")
+        if st.packed is None or st.packed.numel() < sz.value or st.packed.device != device:
+            st.packed = torch.empty(sz.value, dtype=torch.uint8, device=device)
+        stream = C.c_void_p(torch.cuda.current_stream(device).cuda_stream)
+        _lib.check(lib.rf_pack_params(st.handle, C.c_void_p(st.packed.data_ptr()), sz.value, stream), "rf_pack_params")
+        st.signature = sig
+
+    def _run(self, x: torch.Tensor, packed_input: bool) -> torch.Tensor:
+        if x.device.type != "cuda":
+            raise RuntimeError("RawFormer (HIP) needs a ROCm device tensor: there is no CPU path in this package "
+                               f"(input is on {x.device})")
+        if x.dim() != 4:
+            raise RuntimeError(f"expected a 4-D input [B,C,H,W], got {tuple(x.shape)}")
+        if torch.is_grad_enabled() and self.training and any(p.requires_grad for p in self.parameters()):
+            raise RuntimeError("RawFormer (HIP) implements inference only: call model.eval() or wrap in torch.no_grad() "
+                               "(the training step is a later row of SURVEY.md section 8f)")
+        x = x.detach()
+        if x.dtype != torch.float32:
+            x = x.float()
+        x = x.contiguous()
+        b, c, h, w = x.shape
+        if packed_input:
+            if c != 4 * self.inp_channels:
+                raise RuntimeError(f"expected {4 * self.inp_channels} packed channels, got {c}")
+            H, W = h, w
+        else:
+            if c != self.inp_channels:
+                raise RuntimeError(f"Given a mosaic with {c} channels, expected {self.inp_channels}")
+            if h % 2 or w % 2:
+                raise RuntimeError(f"mosaic size {h}x{w} must be even")
+            H, W = h // 2, w // 2
+        if H % 8 or W % 8:
+            raise RuntimeError(f"mosaic size must be divisible by 16 (three 2x down-samplings after the Bayer pack); "
+                               f"got {2 * H}x{2 * W}")
+        lib = _lib.load()
+        with torch.cuda.device(x.device):
+            st = self._state_for(x.device)
+            self._sync_params(st, x.device)
+            sz = C.c_size_t()
+            _lib.check(lib.rf_workspace_bytes(st.handle, b, H, W, C.byref(sz)), "rf_workspace_bytes")
+            if st.workspace is None or st.workspace.numel() < sz.value:
+                st.workspace = None
+                st.workspace = torch.empty(sz.value, dtype=torch.uint8, device=x.device)
+            out = torch.empty((b, self.out_channels, 2 * H, 2 * W), dtype=torch.float32, device=x.device)
+            stream = C.c_void_p(torch.cuda.current_stream(x.device).cuda_stream)
+            _lib.check(lib.rf_forward(st.handle, C.c_void_p(x.data_ptr()), C.c_void_p(out.data_ptr()),
+                                      C.c_void_p(st.workspace.data_ptr()), st.workspace.numel(), b, H, W,
+                                      int(packed_input), stream), "rf_forward")
+        return out
+
+    def forward(self, x: torch.Tensor) -> torch.Tensor:
+        """Mosaic ``[B, inp_channels, 2H, 2W]`` -> ``[B, out_channels, 2H, 2W]`` (test.py:116)."""
+        return self._run(x, packed_input=False)
+
+    def forward_packed(self, x4: torch.Tensor) -> torch.Tensor:
+        """Packed RGGB ``[B, 4, H, W]`` (the ``downshuffle`` already applied) -> ``[B, 3, 2H, 2W]``."""
+        return self._run(x4, packed_input=True)
+
+    def workspace_bytes(self, batch: int, H: int, W: int) -> int:
+        probe, sz = C.c_void_p(), C.c_size_t()
+        cfg = self._config()
+        lib = _lib.load()
+        _lib.check(lib.rf_create(C.byref(cfg), C.byref(probe)), "rf_create")
+        try:
+            _lib.check(lib.rf_workspace_bytes(probe, batch, H, W, C.byref(sz)), "rf_workspace_bytes")
+        finally:
+            lib.rf_destroy(probe)
+        return sz.value
+
+    def __del__(self):
+        try:
+            if getattr(self, "_rt_owner", None) != id(self):
+                return
+            lib = _lib.load()
+            for st in getattr(self, "_rt", {}).values():
+                if st.handle:
+                    lib.rf_destroy(st.handle)
+                    st.handle = C.c_void_p()
+        except Exception:
+            pass

@@ -1,0 +1,269 @@
+"""Operator-level Python surface over the C ABI (same kernels the whole forward uses).
+
+Function names and argument meaning follow the reference's Python
+(``downshuffle``, ``dwt_init`` / ``iwt_init``, ``CustomDWT`` / ``CustomIDWT``, ``HaarDWT``,
+``LayerNorm``, ``Attention`` ...), so the parity tests read like calls into the reference.
+Tensors must be float32, contiguous, on a ROCm device; torch is only the allocator and the
+stream provider here.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Optional, Sequence, Tuple
+
+import torch
+
+from . import _lib
+
+
+def _chk(t: torch.Tensor, name: str) -> torch.Tensor:
+    if not isinstance(t, torch.Tensor):
+        raise TypeError(f"{name}: expected a torch.Tensor")
+    if t.device.type != "cuda":
+        raise RuntimeError(f"{name}: tensor is on {t.device}; the RawFormer HIP path has no CPU implementation")
+    if t.dtype != torch.float32:
+        raise RuntimeError(f"{name}: expected float32, got {t.dtype}")
+    return t.contiguous()
+
+
+def _ptr(t: Optional[torch.Tensor]):
+    return None if t is None else C.c_void_p(t.data_ptr())
+
+
+def _stream(t: torch.Tensor):
+    return C.c_void_p(torch.cuda.current_stream(t.device).cuda_stream)
+
+
+def _scratch(nbytes: int, like: torch.Tensor) -> torch.Tensor:
+    return torch.empty(max(nbytes, 16), dtype=torch.uint8, device=like.device)
+
+
+def downshuffle(x: torch.Tensor, r: int = 2) -> torch.Tensor:
+    """``downshuffle(var, 2)`` (RawFomer_WFB_FFAB/model.py:287-298): [B,C,2h,2w] -> [B,4C,h,w]."""
+    if r != 2:
+        raise ValueError("only r=2 is used by RawFormer")
+    x = _chk(x, "x")
+    b, c, h2, w2 = x.shape
+    if h2 % 2 or w2 % 2:
+        raise RuntimeError(f"downshuffle: spatial size {h2}x{w2} not divisible by 2")
+    out = torch.empty((b, 4 * c, h2 // 2, w2 // 2), dtype=x.dtype, device=x.device)
+    with torch.cuda.device(x.device):
+        _lib.check(_lib.load().rf_pixel_unshuffle2(_ptr(x), _ptr(out), b, c, h2 // 2, w2 // 2, _stream(x)), "rf_pixel_unshuffle2")
+    return out
+
+
+def pixel_shuffle(x: torch.Tensor, r: int = 2) -> torch.Tensor:
+    """``nn.PixelShuffle(2)`` (RawFomer_WFB_FFAB/model.py:471,507): [B,4C,h,w] -> [B,C,2h,2w]."""
+    if r != 2:
+        raise ValueError("only r=2 is used by RawFormer")
+    x = _chk(x, "x")
+    b, c4, h, w = x.shape
+    if c4 % 4:
+        raise RuntimeError(f"pixel_shuffle: {c4} channels not divisible by 4")
+    out = torch.empty((b, c4 // 4, 2 * h, 2 * w), dtype=x.dtype, device=x.device)
+    with torch.cuda.device(x.device):
+        _lib.check(_lib.load().rf_pixel_shuffle2(_ptr(x), _ptr(out), b, c4 // 4, h, w, _stream(x)), "rf_pixel_shuffle2")
+    return out
+
+
+def dwt_init(x: torch.Tensor) -> torch.Tensor:
+    """``dwt_init`` / ``DWT`` (RawFomer_WFB_FFAB/blocks.py:102-115): [B,C,2h,2w] -> [4B,C,h,w]."""
+    x = _chk(x, "x")
+    b, c, h2, w2 = x.shape
+    if h2 % 2 or w2 % 2:
+        raise RuntimeError(f"dwt_init: spatial size {h2}x{w2} not divisible by 2")
+    out = torch.empty((4 * b, c, h2 // 2, w2 // 2), dtype=x.dtype, device=x.device)
+    with torch.cuda.device(x.device):
+        _lib.check(_lib.load().rf_dwt_haar(_ptr(x), _ptr(out), b, c, h2 // 2, w2 // 2, _stream(x)), "rf_dwt_haar")
+    return out
+
+
+def iwt_init(x: torch.Tensor) -> torch.Tensor:
+    """``iwt_init`` / ``IWT`` (RawFomer_WFB_FFAB/blocks.py:119-136): [4B,C,h,w] -> [B,C,2h,2w]."""
+    x = _chk(x, "x")
+    b4, c, h, w = x.shape
+    if b4 % 4:
+        raise RuntimeError(f"iwt_init: batch {b4} not divisible by 4")
+    out = torch.empty((b4 // 4, c, 2 * h, 2 * w), dtype=x.dtype, device=x.device)
+    with torch.cuda.device(x.device):
+        _lib.check(_lib.load().rf_idwt_haar(_ptr(x), _ptr(out), b4 // 4, c, h, w, _stream(x)), "rf_idwt_haar")
+    return out
+
+
+def _k16(kernel: Sequence[Sequence[float]]):
+    flat = [float(v) for row in kernel for v in row]
+    if len(flat) != 16:
+        raise ValueError("kernel must be 4x4")
+    return (C.c_float * 16)(*flat)
+
+
+DEFAULT_KERNEL = ((1, 1, 1, 1), (1, -1, 1, 1), (1, 1, -1, 1), (1, 1, 1, -1))  # README.md:98-103
+
+
+def custom_dwt(x: torch.Tensor, kernel=DEFAULT_KERNEL, norm: bool = True) -> torch.Tensor:
+    """``CustomDWT(kernel, norm=norm)(x)`` (README.md:92-117): [B,C,2h,2w] -> [B,4C,h,w]."""
+    x = _chk(x, "x")
+    b, c, h2, w2 = x.shape
+    if h2 % 2 or w2 % 2:
+        raise RuntimeError(f"CustomDWT: spatial size {h2}x{w2} not divisible by 2")
+    out = torch.empty((b, 4 * c, h2 // 2, w2 // 2), dtype=x.dtype, device=x.device)
+    with torch.cuda.device(x.device):
+        _lib.check(_lib.load().rf_dwt_custom(_ptr(x), _ptr(out), _k16(kernel), int(norm), b, c, h2 // 2, w2 // 2, _stream(x)),
+                   "rf_dwt_custom")
+    return out
+
+
+def custom_idwt(x: torch.Tensor, kernel=DEFAULT_KERNEL, norm: bool = True) -> torch.Tensor:
+    """``CustomIDWT(kernel, norm=norm)(x)`` (README.md:120-144): [B,4C,h,w] -> [B,C,2h,2w]."""
+    x = _chk(x, "x")
+    b, c4, h, w = x.shape
+    if c4 % 4:
+        raise RuntimeError(f"CustomIDWT: {c4} channels not divisible by 4")
+    out = torch.empty((b, c4 // 4, 2 * h, 2 * w), dtype=x.dtype, device=x.device)
+    with torch.cuda.device(x.device):
+        _lib.check(_lib.load().rf_idwt_custom(_ptr(x), _ptr(out), _k16(kernel), int(norm), b, c4 // 4, h, w, _stream(x)),
+                   "rf_idwt_custom")
+    return out
+
+
+def haar_dwt(x: torch.Tensor) -> Tuple[torch.Tensor, Tuple[torch.Tensor, torch.Tensor, torch.Tensor]]:
+    """``HaarDWT()(x)`` (FrequencyawareLumaChromaAttentionRAWFormer.py:39-73): LL, (LH, HL, HH)."""
+    x = _chk(x, "x")
+    b, c, h, w = x.shape
+    out = torch.empty((4, b, c, (h + 1) // 2, (w + 1) // 2), dtype=x.dtype, device=x.device)
+    with torch.cuda.device(x.device):
+        _lib.check(_lib.load().rf_haar_dwt(_ptr(x), _ptr(out), b, c, h, w, _stream(x)), "rf_haar_dwt")
+    return out[0], (out[1], out[2], out[3])
+
+
+def layernorm2d(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor], eps: float = 1e-5) -> torch.Tensor:
+    """``LayerNorm(dim)(x)`` on NCHW (FrequencyawareLumaChromaAttentionRAWFormer.py:180-187);
+    ``bias=None`` is ``BiasFree_LayerNorm`` (RawFomer_WFB_FFAB/model.py:89-103)."""
+    x, weight = _chk(x, "x"), _chk(weight, "weight")
+    bias = None if bias is None else _chk(bias, "bias")
+    b, c, h, w = x.shape
+    if weight.numel() != c:
+        raise RuntimeError(f"LayerNorm: weight has {weight.numel()} elements, input has {c} channels")
+    out = torch.empty_like(x)
+    with torch.cuda.device(x.device):
+        _lib.check(_lib.load().rf_layernorm2d(_ptr(x), _ptr(out), _ptr(weight), _ptr(bias), float(eps), b, c, h, w, _stream(x)),
+                   "rf_layernorm2d")
+    return out
+
+
+def conv1x1(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor] = None, *,
+            x2: Optional[torch.Tensor] = None, ln_weight: Optional[torch.Tensor] = None,
+            ln_bias: Optional[torch.Tensor] = None, residual: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """``nn.Conv2d(Cin, Cout, 1)``; optional fused LayerNorm prologue, ``torch.cat([x, x2], 1)``
+    input and residual add."""
+    x, weight = _chk(x, "x"), _chk(weight, "weight")
+    b, c1, h, w = x.shape
+    c2 = 0
+    if x2 is not None:
+        x2 = _chk(x2, "x2")
+        c2 = x2.shape[1]
+    cout = weight.shape[0]
+    if weight.numel() != cout * (c1 + c2):
+        raise RuntimeError(f"conv1x1: weight {tuple(weight.shape)} does not match {c1 + c2} input channels")
+    lib = _lib.load()
+    sz = C.c_size_t()
+    _lib.check(lib.rf_conv1x1_scratch_bytes(c1 + c2, cout, C.byref(sz)), "rf_conv1x1_scratch_bytes")
+    scratch = _scratch(sz.value, x)
+    out = torch.empty((b, cout, h, w), dtype=x.dtype, device=x.device)
+    args = [None if t is None else _chk(t, "arg") for t in (bias, ln_weight, ln_bias, residual)]
+    with torch.cuda.device(x.device):
+        _lib.check(lib.rf_conv1x1(_ptr(x), _ptr(x2), _ptr(out), _ptr(weight), _ptr(args[0]), _ptr(args[1]), _ptr(args[2]),
+                                  _ptr(args[3]), _ptr(scratch), b, c1, c2, cout, h, w, _stream(x)), "rf_conv1x1")
+    return out
+
+
+def dwconv3x3(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor] = None, gelu: bool = False) -> torch.Tensor:
+    """``nn.Conv2d(C, C, 3, padding=1, groups=C)`` (+ exact GELU)."""
+    x, weight = _chk(x, "x"), _chk(weight, "weight")
+    bias = None if bias is None else _chk(bias, "bias")
+    b, c, h, w = x.shape
+    if weight.numel() != c * 9:
+        raise RuntimeError(f"dwconv3x3: weight {tuple(weight.shape)} does not match {c} channels")
+    out = torch.empty_like(x)
+    with torch.cuda.device(x.device):
+        _lib.check(_lib.load().rf_dwconv3x3(_ptr(x), _ptr(out), _ptr(weight), _ptr(bias), int(gelu), b, c, h, w, _stream(x)),
+                   "rf_dwconv3x3")
+    return out
+
+
+def conv3x3(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor] = None, act: str = "none",
+            store: str = "plain") -> torch.Tensor:
+    """``nn.Conv2d(Cin, Cout, 3, padding=1)``; ``act='lrelu'`` adds LeakyReLU(0.2);
+    ``store='unshuffle'`` = Downsample (a8), ``'shuffle'`` = conv_out + PixelShuffle (a10)."""
+    x, weight = _chk(x, "x"), _chk(weight, "weight")
+    bias = None if bias is None else _chk(bias, "bias")
+    b, cin, h, w = x.shape
+    cout = weight.shape[0]
+    if tuple(weight.shape[1:]) != (cin, 3, 3):
+        raise RuntimeError(f"conv3x3: weight {tuple(weight.shape)} does not match {cin} input channels")
+    mode = {"plain": 0, "unshuffle": 1, "shuffle": 2}[store]
+    shape = {0: (b, cout, h, w), 1: (b, cout * 4, h // 2, w // 2), 2: (b, cout // 4, 2 * h, 2 * w)}[mode]
+    lib = _lib.load()
+    sz = C.c_size_t()
+    _lib.check(lib.rf_conv3x3_scratch_bytes(cin, cout, C.byref(sz)), "rf_conv3x3_scratch_bytes")
+    scratch = _scratch(sz.value, x)
+    out = torch.empty(shape, dtype=x.dtype, device=x.device)
+    with torch.cuda.device(x.device):
+        _lib.check(lib.rf_conv3x3(_ptr(x), _ptr(out), _ptr(weight), _ptr(bias), _ptr(scratch), {"none": 0, "lrelu": 1}[act], mode,
+                                  b, cin, cout, h, w, _stream(x)), "rf_conv3x3")
+    return out
+
+
+def conv_transpose2x2(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """``nn.ConvTranspose2d(Cin, Cout, 2, stride=2)`` (RawFomer_WFB_FFAB/model.py:461)."""
+    x, weight = _chk(x, "x"), _chk(weight, "weight")
+    bias = None if bias is None else _chk(bias, "bias")
+    b, cin, h, w = x.shape
+    if weight.shape[0] != cin or tuple(weight.shape[2:]) != (2, 2):
+        raise RuntimeError(f"ConvTranspose2d: weight {tuple(weight.shape)} does not match {cin} input channels")
+    cout = weight.shape[1]
+    lib = _lib.load()
+    sz = C.c_size_t()
+    _lib.check(lib.rf_convT2x2_scratch_bytes(cin, cout, C.byref(sz)), "rf_convT2x2_scratch_bytes")
+    scratch = _scratch(sz.value, x)
+    out = torch.empty((b, cout, 2 * h, 2 * w), dtype=x.dtype, device=x.device)
+    with torch.cuda.device(x.device):
+        _lib.check(lib.rf_convT2x2(_ptr(x), _ptr(out), _ptr(weight), _ptr(bias), _ptr(scratch), b, cin, cout, h, w, _stream(x)),
+                   "rf_convT2x2")
+    return out
+
+
+def channel_attention(x: torch.Tensor, qkv_w, qkv_b, dw_w, dw_b, temperature, proj_w, proj_b, heads: int) -> torch.Tensor:
+    """``Attention(dim, heads, bias=True)(x)`` (FrequencyawareLumaChromaAttentionRAWFormer.py:212-235)."""
+    x = _chk(x, "x")
+    ts = [None if t is None else _chk(t, "param") for t in (qkv_w, qkv_b, dw_w, dw_b, temperature, proj_w, proj_b)]
+    b, c, h, w = x.shape
+    if c % heads:
+        raise RuntimeError(f"Attention: {c} channels not divisible by {heads} heads")
+    lib = _lib.load()
+    sz = C.c_size_t()
+    _lib.check(lib.rf_chan_attn_scratch_bytes(b, c, heads, h, w, C.byref(sz)), "rf_chan_attn_scratch_bytes")
+    scratch = _scratch(sz.value, x)
+    out = torch.empty_like(x)
+    with torch.cuda.device(x.device):
+        _lib.check(lib.rf_chan_attn(_ptr(x), _ptr(out), *[_ptr(t) for t in ts], _ptr(scratch), b, c, heads, h, w, _stream(x)),
+                   "rf_chan_attn")
+    return out
+
+
+def flca_guidance(x4: torch.Tensor, size: Tuple[int, int]) -> torch.Tensor:
+    """Guidance planes ``[y_low, y_high, cr, cb]`` an FLCA block sees at feature size ``size``
+    (``BayerLumaChroma`` + ``HaarDWT`` + bilinear ``F.interpolate``,
+    FrequencyawareLumaChromaAttentionRAWFormer.py:79-97,138-149)."""
+    x4 = _chk(x4, "x4")
+    b, c, h, w = x4.shape
+    if c != 4:
+        raise RuntimeError("flca_guidance expects packed RGGB [B,4,H,W]")
+    lib = _lib.load()
+    sz = C.c_size_t()
+    _lib.check(lib.rf_guidance_scratch_bytes(b, h, w, C.byref(sz)), "rf_guidance_scratch_bytes")
+    scratch = _scratch(sz.value, x4)
+    out = torch.empty((b, 4, size[0], size[1]), dtype=x4.dtype, device=x4.device)
+    with torch.cuda.device(x4.device):
+        _lib.check(lib.rf_flca_guidance(_ptr(x4), _ptr(out), _ptr(scratch), b, h, w, size[0], size[1], _stream(x4)), "rf_flca_guidance")
+    return out

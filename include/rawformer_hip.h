@@ -54,6 +54,13 @@ typedef struct rf_config {
 const char* rf_last_error(void);
 int rf_version(void);
 
+/* Diagnostic: bracket every kernel launch made by this library between the two calls with
+ * HIP events on the launch stream; rf_profile_end writes a JSON array of
+ * {kernel, launches, ms, flops, bytes} (algorithmic work per kernel class) into `json`.
+ * Single-threaded use only; adds event overhead, so never leave it on in a timed region. */
+int rf_profile_begin(void);
+int rf_profile_end(char* json, size_t len);
+
 /* ---- whole model: RawFormer.__init__/load_state_dict/forward ------------------------------ */
 int rf_create(const rf_config* cfg, rf_handle** out);
 void rf_destroy(rf_handle* h);
