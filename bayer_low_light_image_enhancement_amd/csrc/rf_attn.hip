@@ -34,7 +34,7 @@ int gram_plan(int B, int C, int heads, int P, int* nslab, int* slab, size_t* par
     const int NTq = cdiv(C, 16);
     // the slab split depends only on (C, P), never on B: an image's result is bitwise the same
     // alone and inside a batch
-    int ns = cdiv(256, NTq);
+    int ns = cdiv(P, 4096);
     const int maxs = cdiv(P, 256);
     if (ns > maxs) ns = maxs;
     if (ns < 1) ns = 1;

@@ -3,13 +3,17 @@
 //
 // Workgroup = 4 waves; it owns a (4*RW rows) x (64/RW cols) pixel tile and NCO*16 output
 // channels.  Per 8-input-channel chunk the halo'd input tile and the matching slice of the
-// lane-ordered packed weights are staged in LDS; every wave then walks 2 k-sets x 9 taps.
+// lane-ordered packed weights sit in LDS; every wave then walks 2 k-sets x 9 taps.
 //   * B operand: lane (kq, j) owns 4 consecutive pixels of one row.  Two ds_read_b128 per
 //     (k-set, dy) fetch the 6 neighbours those pixels need; tap dx of pixel g is v[g + dx], so
 //     one LDS read feeds 12 * NCO MFMAs.  The plane stride (448 floats) keeps the four kq
 //     planes on disjoint LDS slots.
 //   * A operand: ds_read_b32, lane-linear (conflict-free).
 //   * D: channels 16t + 4kq + r for the lane's 4 pixels -> 16-byte stores.
+// Pipeline: LDS is double buffered; the global loads of chunk c+1 (input tile with zero
+// padding, weight slice) are issued into registers before the MFMA block of chunk c and written
+// to the other LDS buffer after it: one barrier per chunk, HBM/L2 latency hidden behind the
+// matrix pipe.  Per-thread gather offsets are computed once, not per chunk.
 // Fused: Bayer pack on the input side (a1, the embedding conv reads the mosaic directly),
 // input/output clamps, bias, LeakyReLU(0.2), and the pixel-unshuffle (Downsample, a8) or
 // pixel-shuffle (conv_out + PixelShuffle, a10) store.
@@ -22,15 +26,18 @@ static constexpr int KC = 8;        // input channels per LDS chunk
 static constexpr int PS = 448;      // LDS plane stride in floats (multiple of 64)
 
 template <int NCO, int LOG2_RW>
-__global__ void __launch_bounds__(256) conv3x3_kernel(Conv3x3Args a, int ngroups, int tiles_x, int vec) {
+__global__ void __launch_bounds__(256, 2) conv3x3_kernel(Conv3x3Args a, int ngroups, int tiles_x, int vec) {
     constexpr int RW = 1 << LOG2_RW;         // rows per wave
     constexpr int TW = 64 / RW;              // tile width
     constexpr int TH = 4 * RW;               // tile height
     constexpr int RS = TW + 8;               // LDS row stride
     static_assert((TH + 2) * RS <= PS, "plane does not fit");
-    __shared__ __attribute__((aligned(16))) float lds[KC * PS + 2 * 9 * NCO * 64];
-    float* lds_in = lds;
-    float* lds_w = lds + KC * PS;
+    constexpr int NIN = KC * (TH + 2) * (TW + 2);       // staged input elements per chunk
+    constexpr int EPT = (NIN + 255) / 256;              // ... per thread
+    constexpr int NW4 = 2 * 9 * NCO * 16;               // staged weight float4 per chunk
+    constexpr int WPT = (NW4 + 255) / 256;
+    constexpr int BUF = KC * PS + 2 * 9 * NCO * 64;     // floats per LDS buffer
+    __shared__ __attribute__((aligned(16))) float lds[2 * BUF];
 
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
@@ -46,6 +53,63 @@ __global__ void __launch_bounds__(256) conv3x3_kernel(Conv3x3Args a, int ngroups
     const int t0 = grp * NCO;
     const int nchunks = (a.Cin + KC - 1) / KC;
     const float* xb = a.x + (size_t)b * a.x_bstride;
+    const size_t chunk_stride = a.unshuffle_in ? (size_t)(KC / 4) * 4 * h * w : (size_t)KC * h * w;
+
+    // ---- per-thread gather plan for the input tile (same for every chunk up to the channel base)
+    int goff[EPT];        // offset inside the chunk's KC planes, or -1 = zero padding / beyond the tile
+    short loff[EPT];      // LDS offset inside the buffer
+    short gcl[EPT];       // channel inside the chunk
+#pragma unroll
+    for (int i = 0; i < EPT; ++i) {
+        const int idx = tid + 256 * i;
+        const int c = idx % (TW + 2);
+        const int r = (idx / (TW + 2)) % (TH + 2);
+        const int cl = idx / ((TW + 2) * (TH + 2));
+        const int y = y0 - 1 + r, x = x0 - 1 + c;
+        const bool ok = idx < NIN && y >= 0 && y < h && x >= 0 && x < w;
+        int off;
+        if (a.unshuffle_in)   // packed channel cl = 2*i + jj of mosaic plane 0 lives at (2y+i, 2x+jj); KC = 8 covers 2 planes
+            off = ((cl >> 2) * 2 * h + 2 * y + ((cl >> 1) & 1)) * (2 * w) + 2 * x + (cl & 1);
+        else
+            off = (cl * h + y) * w + x;
+        goff[i] = ok ? off : -1;
+        loff[i] = (short)(idx < NIN ? cl * PS + r * RS + c : -1);
+        gcl[i] = (short)cl;
+    }
+    float xin[EPT];
+    float4 win[WPT];
+    auto load_chunk = [&](int ch) {
+        const float* src = xb + (size_t)ch * chunk_stride;
+#pragma unroll
+        for (int i = 0; i < EPT; ++i) {
+            const bool ok = goff[i] >= 0 && ch * KC + gcl[i] < a.Cin;
+            float v = src[ok ? goff[i] : 0];          // branch-free: clamped address, value masked below
+            if (a.clamp_in) v = fminf(fmaxf(v, 0.f), 1.f);
+            xin[i] = ok ? v : 0.f;
+        }
+#pragma unroll
+        for (int i = 0; i < WPT; ++i) {
+            const int idx = tid + 256 * i;
+            const int l4 = idx % 16;
+            const int t = (idx / 16) % NCO;
+            const int kt = idx / (16 * NCO);          // ks * 9 + tap
+            const bool ok = idx < NW4 && t0 + t < NT;
+            const float4 v = *reinterpret_cast<const float4*>(a.wp + (((size_t)(ch * 2) * 9 + (ok ? kt : 0)) * NT + t0 + (ok ? t : 0)) * 64 + l4 * 4);
+            win[i] = ok ? v : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+    };
+    auto store_chunk = [&](int buf) {
+        float* li = lds + buf * BUF;
+        float* lw = li + KC * PS;
+#pragma unroll
+        for (int i = 0; i < EPT; ++i)
+            if (loff[i] >= 0) li[loff[i]] = xin[i];
+#pragma unroll
+        for (int i = 0; i < WPT; ++i) {
+            const int idx = tid + 256 * i;
+            if (idx < NW4) *reinterpret_cast<float4*>(lw + idx * 4) = win[i];   // [kt][t][64] is linear in idx
+        }
+    };
 
     f32x4 acc[NCO][4];
 #pragma unroll
@@ -53,39 +117,13 @@ __global__ void __launch_bounds__(256) conv3x3_kernel(Conv3x3Args a, int ngroups
 #pragma unroll
         for (int g = 0; g < 4; ++g) acc[t][g] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
+    load_chunk(0);
+    store_chunk(0);
+    __syncthreads();
     for (int ch = 0; ch < nchunks; ++ch) {
-        __syncthreads();   // previous chunk fully consumed
-        // ---- stage the input tile (zero padding outside the image / beyond Cin)
-        constexpr int NIN = KC * (TH + 2) * (TW + 2);
-        for (int idx = tid; idx < NIN; idx += 256) {
-            const int c = idx % (TW + 2);
-            const int r = (idx / (TW + 2)) % (TH + 2);
-            const int cl = idx / ((TW + 2) * (TH + 2));
-            const int ci = ch * KC + cl;
-            const int y = y0 - 1 + r, x = x0 - 1 + c;
-            float v = 0.f;
-            if (ci < a.Cin && y >= 0 && y < h && x >= 0 && x < w) {
-                if (a.unshuffle_in)   // packed channel ci = 4*c0 + 2*i + jj lives at mosaic (2y+i, 2x+jj)
-                    v = xb[((size_t)(ci >> 2) * 2 * h + 2 * y + ((ci >> 1) & 1)) * (size_t)(2 * w) + 2 * x + (ci & 1)];
-                else
-                    v = xb[((size_t)ci * h + y) * w + x];
-                if (a.clamp_in) v = fminf(fmaxf(v, 0.f), 1.f);
-            }
-            lds_in[cl * PS + r * RS + c] = v;
-        }
-        // ---- stage the weight slice: [2 k-sets][9 taps][NCO tiles][64 lanes]
-        constexpr int NW4 = 2 * 9 * NCO * 16;
-        for (int idx = tid; idx < NW4; idx += 256) {
-            const int l4 = idx % 16;
-            const int t = (idx / 16) % NCO;
-            const int kt = idx / (16 * NCO);          // ks * 9 + tap
-            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (t0 + t < NT)
-                v = *reinterpret_cast<const float4*>(a.wp + (((size_t)(ch * 2) * 9 + kt) * NT + t0 + t) * 64 + l4 * 4);
-            *reinterpret_cast<float4*>(lds_w + (kt * NCO + t) * 64 + l4 * 4) = v;
-        }
-        __syncthreads();
-        // ---- 2 k-sets x 9 taps on the matrix cores
+        if (ch + 1 < nchunks) load_chunk(ch + 1);       // in flight during the MFMA block below
+        const float* lds_in = lds + (ch & 1) * BUF;
+        const float* lds_w = lds_in + KC * PS;
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
             const float* lp = lds_in + (ks * 4 + kq) * PS + (wave * RW + rowj) * RS + 4 * cg;
@@ -107,6 +145,8 @@ __global__ void __launch_bounds__(256) conv3x3_kernel(Conv3x3Args a, int ngroups
                 }
             }
         }
+        if (ch + 1 < nchunks) store_chunk((ch + 1) & 1);   // the other buffer: last read one barrier ago
+        __syncthreads();
     }
 
     // ---- epilogue
@@ -208,7 +248,8 @@ int launch_conv3x3(const Conv3x3Args& a, hipStream_t st) {
     RF_CHECK_ARG(a.B > 0 && a.B <= 65535 && a.Cin > 0 && a.Cout > 0 && a.h > 0 && a.w > 0, "conv3x3: bad sizes");
     RF_CHECK_ARG(a.store == 0 || (a.store == 1 && a.h % 2 == 0 && a.w % 2 == 0) || (a.store == 2 && a.Cout % 4 == 0),
                  "conv3x3: store mode %d incompatible with Cout=%d h=%d w=%d", a.store, a.Cout, a.h, a.w);
-    RF_CHECK_ARG(!a.unshuffle_in || a.Cin % 4 == 0, "conv3x3: packed input needs Cin %% 4 == 0");
+    RF_CHECK_ARG(!a.unshuffle_in || a.Cin == 4, "conv3x3: the packed-mosaic input path takes exactly 4 channels");
+    RF_CHECK_ARG((double)a.Cin * a.h * a.w * 4.0 < 2.0e9, "conv3x3: image too large for 32-bit gather offsets");
     const int NT = cdiv(a.Cout, 16);
     int nco = 4;
     if (NT % 4 != 0) nco = (NT % 3 == 0) ? 3 : (NT % 2 == 0 ? 2 : (NT == 1 ? 1 : 4));

@@ -64,7 +64,13 @@ __global__ void __launch_bounds__(256) guide_luma_kernel(const float* __restrict
     }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
-    if ((threadIdx.x & 63) == 0 && m > -INFINITY) atomic_max_float(amax + b, m);
+    __shared__ float wm[4];
+    if ((threadIdx.x & 63) == 0) wm[threadIdx.x >> 6] = m;
+    __syncthreads();
+    if (threadIdx.x == 0) {   // one atomic per workgroup: all of an image's atomics hit one address
+        m = fmaxf(fmaxf(wm[0], wm[1]), fmaxf(wm[2], wm[3]));
+        if (m > -INFINITY) atomic_max_float(amax + b, m);
+    }
 }
 
 // normalise luma, chroma differences, Haar LL / high-band magnitude (one thread per 2x2 block)
@@ -104,7 +110,8 @@ int launch_guidance_base(const float* in, int mosaic, int clamp_in, float* scrat
     guide_init_kernel<<<cdiv(B, 256), 256, 0, st>>>(g.amax, B);
     const size_t hw = (size_t)H * W;
     int gx = (int)((hw + 255) / 256);
-    if (gx > 1024) gx = 1024;
+    const int cap = 2048 / B > 32 ? 2048 / B : 32;   // grid-stride: few workgroups (= few atomics) per image
+    if (gx > cap) gx = cap;
     guide_luma_kernel<<<dim3((unsigned)gx, (unsigned)B), 256, 0, st>>>(in, mosaic, clamp_in, g.y, g.amax, H, W);
     int gx2 = (int)((hw / 4 + 255) / 256);
     if (gx2 > 1024) gx2 = 1024;
@@ -215,20 +222,32 @@ int launch_flca_spatial(const FlcaSpatialArgs& a, hipStream_t st) {
     return check_launch("flca_spatial");
 }
 
-__global__ void __launch_bounds__(256) flca_se_fold_kernel(const float* __restrict__ partial, int nblk, int P,
-                                                           const float* __restrict__ se1_w, const float* __restrict__ se1_b,
-                                                           const float* __restrict__ se3_w, const float* __restrict__ se3_b, int hidden,
-                                                           const float* __restrict__ w_cr, float* __restrict__ wp_out,
-                                                           float* __restrict__ ch_out, int C) {
+// squeeze-excite gate of one image: pooled mean (fixed-order reduction of the per-block sums,
+// all 256 threads busy: thread = (block slice, channel)), 2-layer MLP, sigmoid
+__global__ void __launch_bounds__(256) flca_se_kernel(const float* __restrict__ partial, int nblk, int P,
+                                                      const float* __restrict__ se1_w, const float* __restrict__ se1_b,
+                                                      const float* __restrict__ se3_w, const float* __restrict__ se3_b, int hidden,
+                                                      float* __restrict__ ch_out, int C) {
     const size_t b = blockIdx.x;
-    __shared__ float mean[512], hid[64], ch[512];
-    for (int c = threadIdx.x; c < C; c += 256) {
-        const float* src = partial + b * nblk * C + c;
+    __shared__ float part[256], mean[512], hid[64];
+    const int cw = C < 256 ? C : 256;          // channels handled per pass
+    const int nsl = 256 / cw;                  // block slices summed in parallel (C is a multiple of 8)
+    for (int c0 = 0; c0 < C; c0 += cw) {
+        const int c = c0 + threadIdx.x % cw, sl = threadIdx.x / cw;
         float s = 0.f;
-        for (int k = 0; k < nblk; ++k) s += src[(size_t)k * C];
-        mean[c] = s / (float)P;
+        if (sl < nsl && c < C) {
+            const float* src = partial + b * nblk * C + c;
+            for (int k = sl; k < nblk; k += nsl) s += src[(size_t)k * C];
+        }
+        part[threadIdx.x] = s;
+        __syncthreads();
+        if (threadIdx.x < cw && c0 + threadIdx.x < C) {
+            float t = 0.f;
+            for (int q = 0; q < nsl; ++q) t += part[q * cw + threadIdx.x];
+            mean[c0 + threadIdx.x] = t / (float)P;
+        }
+        __syncthreads();
     }
-    __syncthreads();
     for (int m = threadIdx.x; m < hidden; m += 256) {
         float s = se1_b[m];
         for (int c = 0; c < C; ++c) s = fmaf(se1_w[m * C + c], mean[c], s);
@@ -238,18 +257,21 @@ __global__ void __launch_bounds__(256) flca_se_fold_kernel(const float* __restri
     for (int c = threadIdx.x; c < C; c += 256) {
         float s = se3_b[c];
         for (int m = 0; m < hidden; ++m) s = fmaf(se3_w[c * hidden + m], hid[m], s);
-        const float v = 1.0f / (1.0f + expf(-s));
-        ch[c] = v;
-        if (ch_out) ch_out[b * C + c] = v;
+        ch_out[b * C + c] = 1.0f / (1.0f + expf(-s));
     }
-    __syncthreads();
+}
+
+// wp_out[b] = pack([W_a diag(ch_b) | W_b]) in MFMA operand order
+__global__ void __launch_bounds__(256) flca_fold_kernel(const float* __restrict__ w_cr, const float* __restrict__ ch,
+                                                        float* __restrict__ wp_out, int C) {
+    const size_t b = blockIdx.y;
     const int NT = (C + 15) >> 4, NS = (2 * C) >> 2;
     float* dst = wp_out + b * (size_t)NT * NS * 64;
-    for (int idx = threadIdx.x; idx < NT * NS * 64; idx += 256) {
+    for (int idx = blockIdx.x * 256 + threadIdx.x; idx < NT * NS * 64; idx += gridDim.x * 256) {
         const int l = idx & 63, t = (idx >> 6) % NT, s = (idx >> 6) / NT;
         const int co = 16 * t + (l & 15), k = 4 * s + (l >> 4);
         float v = 0.f;
-        if (co < C) v = w_cr[(size_t)co * 2 * C + k] * (k < C ? ch[k] : 1.0f);
+        if (co < C) v = w_cr[(size_t)co * 2 * C + k] * (k < C ? ch[b * C + k] : 1.0f);
         dst[idx] = v;
     }
 }
@@ -257,9 +279,12 @@ __global__ void __launch_bounds__(256) flca_se_fold_kernel(const float* __restri
 int launch_flca_se_fold(const float* partial, int nblk, int P, const float* se1_w, const float* se1_b,
                         const float* se3_w, const float* se3_b, int hidden, const float* w_cr,
                         float* wp_out, float* ch_out, int B, int C, hipStream_t st) {
-    RF_CHECK_ARG(C <= 512 && hidden <= 64 && C % 2 == 0, "flca_se: C=%d hidden=%d unsupported", C, hidden);
-    ProfScope prof(st, "flca_se_fold_kernel", 0.0, 0.0);
-    flca_se_fold_kernel<<<B, 256, 0, st>>>(partial, nblk, P, se1_w, se1_b, se3_w, se3_b, hidden, w_cr, wp_out, ch_out, C);
+    RF_CHECK_ARG(C <= 512 && hidden <= 64 && C % 8 == 0 && ch_out, "flca_se: C=%d hidden=%d unsupported", C, hidden);
+    ProfScope prof(st, "flca_se_kernel+flca_fold_kernel", 0.0, 0.0);
+    flca_se_kernel<<<B, 256, 0, st>>>(partial, nblk, P, se1_w, se1_b, se3_w, se3_b, hidden, ch_out, C);
+    int gx = cdiv(cdiv(C, 16) * (C / 2) * 64, 256 * 4);
+    if (gx < 1) gx = 1;
+    flca_fold_kernel<<<dim3((unsigned)gx, (unsigned)B), 256, 0, st>>>(w_cr, ch_out, wp_out, C);
     return check_launch("flca_se_fold");
 }
 

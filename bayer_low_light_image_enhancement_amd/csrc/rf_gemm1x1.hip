@@ -1,0 +1,545 @@
+// 1x1 convolution = per-image GEMM  out[co][p] = sum_k W[co][k] * x[k][p]  on the f32 matrix
+// cores (v_mfma_f32_16x16x4_f32: exact f32 fmaf chain, so RawFormer keeps reference numerics).
+//
+// Operand mapping (one wave = 64 pixels):
+//   * B: lane (j = l & 15, kq = l >> 4) reads ONE float4 = pixels p0 + 4j .. 4j+3 of channel
+//     4s + kq: 16 lanes cover 256 contiguous bytes of a channel row, one wave instruction 1 KiB.
+//     Component g of that float4 is the B operand of MFMA g, so x never goes through LDS (each
+//     element is used by exactly one wave) and every HBM byte of x is fetched once.
+//   * A: one float per lane from the lane-ordered packed weights, staged in LDS per workgroup
+//     together with the bias and the LayerNorm scale/shift.
+//   * D: lane holds channels 16t + 4kq + r of its 4 pixels -> 16-byte stores, 256 B per 16 lanes.
+// Addresses are (wave-uniform channel base) + (one per-lane 32-bit offset).
+//
+// gfx950 has ONE in-order counter (vmcnt) for loads and stores: a load that is waited for drags
+// every older store with it.  The kernels therefore issue every global load a tile needs
+// (next tile's input, this tile's residual) BEFORE the tile's stores, keep loads branch-free
+// (clamped addresses instead of predicates, so the compiler emits counted waits), and read all
+// small operands (bias, gamma, beta, weights) from LDS, which has its own counter.
+//
+//   conv1x1_res_kernel    K <= 128 (U-Net levels 0-1, HBM-bound): persistent workgroups; a wave
+//                         keeps its whole [K x 64 px] input tile in registers, computes exact
+//                         two-pass LayerNorm statistics on it, then sweeps ALL output-channel
+//                         groups over the resident tile (x is read from HBM once whatever Cout
+//                         is) while the next tile's loads are already in flight (K <= 64).
+//   conv1x1_stream_kernel K  > 128 (levels 2-3, MFMA-bound): accumulators resident, K streamed
+//                         in chunks; the next chunk's x (registers) and weights (registers ->
+//                         LDS double buffer) are fetched while the current one is in the matrix
+//                         pipe; one barrier per chunk.
+//   conv1x1_scalar_kernel any ragged shape (P % 4 != 0 or unaligned): plain FMA loop.
+// Fused: LayerNorm prologue (a4), second source (torch.cat without the copy), bias, residual,
+// LeakyReLU, ConvTranspose2d(k=2,s=2) scatter (a9), per-image weights (wp_bstride != 0) for the
+// attention / squeeze-excite matrices folded into the projection.
+#include <cstdio>
+#include <cstdlib>
+#include "rf_common.h"
+
+namespace rf {
+
+// wave-uniform base of the 4-channel k-set s (channels 4s .. 4s+3 come from one source)
+__device__ __forceinline__ const float* kset_base(const Conv1x1Args& a, int b, int s) {
+    const int k = 4 * s;
+    return (k < a.C1) ? a.x1 + (size_t)b * a.x1_bstride + (size_t)k * a.P
+                      : a.x2 + (size_t)b * a.x2_bstride + (size_t)(k - a.C1) * a.P;
+}
+
+__device__ __forceinline__ float4 ldv(const float* __restrict__ base, unsigned off) {
+    return *reinterpret_cast<const float4*>(base + off);
+}
+
+// Store NCO accumulator tiles.  bias_l: LDS bias of the first tile; res: prefetched residual rows
+// (RES) laid out [tile][r] as float4.
+template <int NCO, bool RES>
+__device__ __forceinline__ void epilogue(const Conv1x1Args& a, f32x4 (&acc)[NCO][4], int tfirst, int ntiles,
+                                         const float* __restrict__ bias_l, const float4* res,
+                                         int b, int p0, int kq, bool live) {
+    const int P = a.P;
+    float* outb = a.out + (size_t)b * a.out_bstride;
+    if (a.mode == 0) {
+        const unsigned voff = (unsigned)(4 * kq) * (unsigned)P + (unsigned)p0;   // channel 4kq of a tile
+#pragma unroll
+        for (int t = 0; t < NCO; ++t) {
+            if (t >= ntiles) break;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int cu = 16 * (tfirst + t) + r;                  // wave-uniform part of the channel
+                const float bs = bias_l[16 * t + 4 * kq + r];
+                float v[4] = {acc[t][0][r] + bs, acc[t][1][r] + bs, acc[t][2][r] + bs, acc[t][3][r] + bs};
+                if constexpr (RES) {
+                    const float4 rv = res[t * 4 + r];
+                    v[0] += rv.x; v[1] += rv.y; v[2] += rv.z; v[3] += rv.w;
+                }
+                if (a.act == 1) {
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) v[g] = v[g] > 0.f ? v[g] : 0.2f * v[g];
+                }
+                if (live && cu + 4 * kq < a.Cout)
+                    *reinterpret_cast<float4*>(outb + (size_t)cu * P + voff) = make_float4(v[0], v[1], v[2], v[3]);
+            }
+        }
+    } else {
+        // ConvTranspose2d(k=2, s=2): GEMM row 4*o + 2*i + jj is output channel o at sub-position
+        // (i, jj); the lane holds the whole 2x2 patch of each of its pixels for channel o.
+        const int w = a.w, w2 = 2 * a.w;
+        const int y = p0 / w, x = p0 - y * w;
+#pragma unroll
+        for (int t = 0; t < NCO; ++t) {
+            if (t >= ntiles) break;
+            const int co = 16 * (tfirst + t) + 4 * kq;
+            const int o = co >> 2;
+            const float bs = bias_l[4 * t + kq];      // bias per real output channel o (staged as [NT*4])
+            float* op = outb + (size_t)o * 4 * P;
+            if (live && co < a.Cout) {
+#pragma unroll
+                for (int i = 0; i < 2; ++i) {
+                    float* row = op + (size_t)(2 * y + i) * w2 + 2 * x;
+                    *reinterpret_cast<float4*>(row) = make_float4(acc[t][0][2 * i] + bs, acc[t][0][2 * i + 1] + bs,
+                                                                  acc[t][1][2 * i] + bs, acc[t][1][2 * i + 1] + bs);
+                    *reinterpret_cast<float4*>(row + 4) = make_float4(acc[t][2][2 * i] + bs, acc[t][2][2 * i + 1] + bs,
+                                                                      acc[t][3][2 * i] + bs, acc[t][3][2 * i + 1] + bs);
+                }
+            }
+        }
+    }
+}
+
+// bias (or zeros) for tiles [tbeg, tbeg + tpad) into LDS; mode 1 stores one value per output channel o
+__device__ __forceinline__ void stage_bias(const Conv1x1Args& a, float* bias_l, int tbeg, int tpad, int tid) {
+    if (a.mode == 0) {
+        for (int i = tid; i < tpad * 16; i += 256) {
+            const int co = 16 * tbeg + i;
+            bias_l[i] = (a.bias && co < a.Cout) ? a.bias[co] : 0.f;
+        }
+    } else {
+        for (int i = tid; i < tpad * 4; i += 256) {
+            const int o = 4 * tbeg + i;
+            bias_l[i] = (a.bias && 4 * o < a.Cout) ? a.bias[o] : 0.f;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Resident-input kernel.  KS = k-sets held in registers (K <= 4 * KS; missing k-sets are
+// duplicates of the last one against zero weights).  A workgroup is persistent over the
+// 256-pixel tiles of ONE image; its weight slice (output tiles [grp*ntw, grp*ntw+ntw), padded to
+// a multiple of NCO = 2) sits in LDS as [KS][tpad][64] floats.  LDS map:
+//   [0, KS*tpad*64) weights | tpad*16 bias | 4*KS gamma | 4*KS beta
+// ---------------------------------------------------------------------------------------------
+template <int KS, bool LN, int RT, bool DBUF>   // RT = residual tiles prefetched per workgroup (0, 2 or 4)
+__global__ void __launch_bounds__(256, (KS <= 8 ? 3 : 2)) conv1x1_res_kernel(Conv1x1Args a, int ntw, int ngroups, int ablate) {
+    constexpr int NCO = 2;
+    constexpr bool RES = RT > 0;
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int j = lane & 15, kq = lane >> 4;
+    const int grp = blockIdx.x % ngroups;
+    const int wg = blockIdx.x / ngroups, nwg = gridDim.x / ngroups;
+    const int b = blockIdx.y;
+    const int P = a.P;
+    const int K = a.C1 + a.C2;
+    const int NS = K >> 2;
+    const int NT = (a.Cout + 15) >> 4;
+    const int tbeg = grp * ntw;
+    const int tcnt = (NT - tbeg < ntw) ? NT - tbeg : ntw;
+    const int tpad = (tcnt + NCO - 1) / NCO * NCO;
+    const int ntiles = (P + 255) >> 8;
+    float* lds_w = lds;
+    float* bias_l = lds + KS * tpad * 64;
+    float* gam_l = bias_l + tpad * 16;
+    float* bet_l = gam_l + 4 * KS;
+
+    // branch-free tile load: dead lanes (p0 >= P) read pixel 0, missing k-sets re-read the last one
+    auto load_tile = [&](int tile, float4 (&dst)[KS]) {
+        const int p0 = (tile * 4 + wave) * 64 + 4 * j;
+        const unsigned voff = (unsigned)kq * (unsigned)P + (unsigned)(p0 < P ? p0 : 0);
+#pragma unroll
+        for (int s = 0; s < KS; ++s) dst[s] = ldv(kset_base(a, b, s < NS ? s : NS - 1), voff);
+    };
+
+    float4 xr[KS], xn[DBUF ? KS : 1];
+    int tile = wg;
+    if (!(ablate & 2)) load_tile(tile < ntiles ? tile : 0, xr);
+    {   // weights, bias, LayerNorm affine -> LDS, once per workgroup (overlaps the first tile's loads)
+        const float* wp = a.wp + (size_t)b * a.wp_bstride;
+        const int n4 = KS * tpad * 16;
+        for (int idx = tid; idx < n4; idx += 256) {
+            const int l4 = idx & 15;
+            const int t = (idx >> 4) % tpad;
+            const int s = (idx >> 4) / tpad;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (t < tcnt && s < NS) v = *reinterpret_cast<const float4*>(wp + ((size_t)s * NT + tbeg + t) * 64 + l4 * 4);
+            *reinterpret_cast<float4*>(lds_w + ((size_t)s * tpad + t) * 64 + l4 * 4) = v;
+        }
+        stage_bias(a, bias_l, tbeg, tpad, tid);
+        if constexpr (LN) {
+            for (int i = tid; i < 4 * KS; i += 256) {
+                gam_l[i] = i < K ? a.ln_w[i] : 0.f;
+                bet_l[i] = (a.ln_b && i < K) ? a.ln_b[i] : 0.f;
+            }
+        }
+    }
+    __syncthreads();
+
+    for (; tile < ntiles; tile += nwg) {
+        const int p0 = (tile * 4 + wave) * 64 + 4 * j;
+        const bool live = p0 < P;
+        const int tnext = tile + nwg;
+        // ---- every global load this iteration needs is issued here, ahead of the tile's stores
+        if constexpr (DBUF) {
+            if (!(ablate & 2)) load_tile(tnext < ntiles ? tnext : tile, xn);
+        }
+        float4 res[RES ? RT * 4 : 1];   // residual rows of this workgroup's output tiles (Cout % 16 == 0 here)
+        if constexpr (RES) {
+            const float* resb = a.res + (size_t)b * a.res_bstride;
+            const unsigned voff = (unsigned)(4 * kq) * (unsigned)P + (unsigned)(live ? p0 : 0);
+#pragma unroll
+            for (int t = 0; t < RT; ++t)
+#pragma unroll
+                for (int r = 0; r < 4; ++r)   // tiles past tcnt re-read the last one: loads stay branch-free
+                    res[t * 4 + r] = ldv(resb + (size_t)(16 * (tbeg + (t < tcnt ? t : tcnt - 1)) + r) * P, voff);
+        }
+        // ---- LayerNorm on the resident tile: exact two-pass statistics over the K channels
+        if constexpr (LN) {
+            float sum[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int s = 0; s < KS; ++s)
+                if (s < NS) { sum[0] += xr[s].x; sum[1] += xr[s].y; sum[2] += xr[s].z; sum[3] += xr[s].w; }
+            const float invK = 1.0f / (float)K;
+            float mu[4], var[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                sum[g] += __shfl_xor(sum[g], 16);
+                sum[g] += __shfl_xor(sum[g], 32);
+                mu[g] = sum[g] * invK;
+            }
+#pragma unroll
+            for (int s = 0; s < KS; ++s) {
+                if (s < NS) {
+                    const float d0 = xr[s].x - mu[0], d1 = xr[s].y - mu[1], d2 = xr[s].z - mu[2], d3 = xr[s].w - mu[3];
+                    var[0] = fmaf(d0, d0, var[0]); var[1] = fmaf(d1, d1, var[1]);
+                    var[2] = fmaf(d2, d2, var[2]); var[3] = fmaf(d3, d3, var[3]);
+                }
+            }
+            float rstd[4], sh[4];
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                var[g] += __shfl_xor(var[g], 16);
+                var[g] += __shfl_xor(var[g], 32);
+                rstd[g] = 1.0f / sqrtf(var[g] * invK + a.ln_eps);
+                sh[g] = a.ln_b ? mu[g] : 0.f;   // BiasFree_LayerNorm keeps the mean in the numerator
+            }
+#pragma unroll
+            for (int s = 0; s < KS; ++s) {
+                const float gk = gam_l[4 * s + kq], bk = bet_l[4 * s + kq];
+                xr[s].x = fmaf((xr[s].x - sh[0]) * rstd[0], gk, bk);
+                xr[s].y = fmaf((xr[s].y - sh[1]) * rstd[1], gk, bk);
+                xr[s].z = fmaf((xr[s].z - sh[2]) * rstd[2], gk, bk);
+                xr[s].w = fmaf((xr[s].w - sh[3]) * rstd[3], gk, bk);
+            }
+        }
+        // ---- sweep the output-channel groups over the resident tile
+        auto do_group = [&](int tg, const float4* resp) {
+            f32x4 acc[NCO][4];
+#pragma unroll
+            for (int t = 0; t < NCO; ++t)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) acc[t][g] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            const float* wl = lds_w + (size_t)tg * 64 + lane;
+#pragma unroll
+            for (int s = 0; s < KS; ++s) {
+                const float xb[4] = {xr[s].x, xr[s].y, xr[s].z, xr[s].w};
+#pragma unroll
+                for (int t = 0; t < NCO; ++t) {
+                    const float av = wl[((size_t)s * tpad + t) * 64];
+#pragma unroll
+                    for (int g = 0; g < 4; ++g)
+                        acc[t][g] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, xb[g], acc[t][g], 0, 0, 0);
+                }
+            }
+            if (!(ablate & 1) || acc[0][0][0] == 1234.5678f)
+                epilogue<NCO, RES>(a, acc, tbeg + tg, tcnt - tg, bias_l + (a.mode == 0 ? 16 : 4) * tg, resp, b, p0, kq, live);
+        };
+        if constexpr (RES) {   // at most two groups, unrolled so the residual registers are indexed statically
+            do_group(0, &res[0]);
+            if constexpr (RT > NCO) {
+                if (tpad > NCO) do_group(NCO, &res[NCO * 4]);
+            }
+        } else {
+#pragma unroll 1
+            for (int tg = 0; tg < tpad; tg += NCO) do_group(tg, res);
+        }
+        if constexpr (DBUF) {
+#pragma unroll
+            for (int s = 0; s < KS; ++s) xr[s] = xn[s];
+        } else {
+            if (tnext < ntiles && !(ablate & 2)) load_tile(tnext, xr);
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Streaming kernel: accumulators for NCO tiles resident, K in chunks of KCH k-sets.
+// ---------------------------------------------------------------------------------------------
+template <int NCO, int KCH, bool LN>
+__global__ void __launch_bounds__(256, 2) conv1x1_stream_kernel(Conv1x1Args a, int ngroups) {
+    __shared__ __attribute__((aligned(16))) float lds_w[2][KCH * NCO * 64];
+    __shared__ float bias_l[NCO * 16];
+    constexpr int WPT = KCH * NCO * 16 / 256;   // float4 of weights each thread moves per chunk
+    static_assert(KCH * NCO * 16 % 256 == 0, "weight chunk must split evenly over the workgroup");
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int j = lane & 15, kq = lane >> 4;
+    const int grp = blockIdx.x % ngroups;
+    const int tile = blockIdx.x / ngroups;
+    const int b = blockIdx.y;
+    const int P = a.P;
+    const int K = a.C1 + a.C2;
+    const int NS = K >> 2;
+    const int NT = (a.Cout + 15) >> 4;
+    const int t0 = grp * NCO;
+    const int tcnt = (NT - t0 < NCO) ? NT - t0 : NCO;
+    const int nch = (NS + KCH - 1) / KCH;
+    const int p0 = (tile * 4 + wave) * 64 + 4 * j;
+    const bool live = p0 < P;
+    const unsigned voff = (unsigned)kq * (unsigned)P + (unsigned)(live ? p0 : 0);
+    const float* wp = a.wp + (size_t)b * a.wp_bstride;
+    stage_bias(a, bias_l, t0, NCO, tid);
+
+    // LayerNorm statistics (shifted single pass; lanes kq = 0..3 split the channels)
+    float lnA[4] = {1.f, 1.f, 1.f, 1.f}, lnB[4] = {0.f, 0.f, 0.f, 0.f};
+    if constexpr (LN) {
+        const float4 s4 = ldv(kset_base(a, b, 0), (unsigned)(live ? p0 : 0));
+        const float sh[4] = {s4.x, s4.y, s4.z, s4.w};
+        float s1[4] = {0.f, 0.f, 0.f, 0.f}, s2[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll 8
+        for (int s = 0; s < NS; ++s) {
+            const float4 t = ldv(kset_base(a, b, s), voff);
+            const float d[4] = {t.x - sh[0], t.y - sh[1], t.z - sh[2], t.w - sh[3]};
+#pragma unroll
+            for (int g = 0; g < 4; ++g) { s1[g] += d[g]; s2[g] = fmaf(d[g], d[g], s2[g]); }
+        }
+        const float invK = 1.0f / (float)K;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            s1[g] += __shfl_xor(s1[g], 16); s1[g] += __shfl_xor(s1[g], 32);
+            s2[g] += __shfl_xor(s2[g], 16); s2[g] += __shfl_xor(s2[g], 32);
+            const float md = s1[g] * invK;
+            const float var = fmaxf(fmaf(-md, md, s2[g] * invK), 0.f);
+            const float rstd = 1.0f / sqrtf(var + a.ln_eps);
+            lnA[g] = rstd;
+            lnB[g] = a.ln_b ? -(sh[g] + md) * rstd : 0.f;
+        }
+    }
+
+    f32x4 acc[NCO][4];
+#pragma unroll
+    for (int t = 0; t < NCO; ++t)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) acc[t][g] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    float4 xc[KCH], xn[KCH], wr[WPT];
+    auto load_x_chunk = [&](int c, float4 (&dst)[KCH]) {
+#pragma unroll
+        for (int i = 0; i < KCH; ++i) {
+            const int s = c * KCH + i;
+            dst[i] = ldv(kset_base(a, b, s < NS ? s : NS - 1), voff);   // k-sets past K meet zero weights
+        }
+    };
+    auto load_w_chunk = [&](int c) {
+#pragma unroll
+        for (int i = 0; i < WPT; ++i) {
+            const int idx = tid + 256 * i;
+            const int l4 = idx & 15, t = (idx >> 4) % NCO, s = c * KCH + (idx >> 4) / NCO;
+            const bool ok = s < NS && t < tcnt;
+            const float4 v = *reinterpret_cast<const float4*>(wp + ((size_t)(ok ? s : 0) * NT + t0 + (ok ? t : 0)) * 64 + l4 * 4);
+            wr[i] = ok ? v : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+    };
+    auto store_w_chunk = [&](int buf) {
+#pragma unroll
+        for (int i = 0; i < WPT; ++i) *reinterpret_cast<float4*>(&lds_w[buf][(tid + 256 * i) * 4]) = wr[i];
+    };
+
+    load_x_chunk(0, xc);
+    load_w_chunk(0);
+    store_w_chunk(0);
+    __syncthreads();
+    for (int c = 0; c < nch; ++c) {
+        if (c + 1 < nch) {   // next chunk in flight while this one computes
+            load_x_chunk(c + 1, xn);
+            load_w_chunk(c + 1);
+        }
+        const float* wl = &lds_w[c & 1][lane];
+#pragma unroll
+        for (int i = 0; i < KCH; ++i) {
+            float xb[4] = {xc[i].x, xc[i].y, xc[i].z, xc[i].w};
+            if constexpr (LN) {
+                const int k = 4 * (c * KCH + i) + kq;
+                const float gk = k < K ? a.ln_w[k] : 0.f, bk = (a.ln_b && k < K) ? a.ln_b[k] : 0.f;
+#pragma unroll
+                for (int g = 0; g < 4; ++g) xb[g] = fmaf(fmaf(xb[g], lnA[g], lnB[g]), gk, bk);
+            }
+#pragma unroll
+            for (int t = 0; t < NCO; ++t) {
+                const float av = wl[(i * NCO + t) * 64];
+#pragma unroll
+                for (int g = 0; g < 4; ++g)
+                    acc[t][g] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, xb[g], acc[t][g], 0, 0, 0);
+            }
+        }
+        if (c + 1 < nch) {
+            store_w_chunk((c + 1) & 1);
+#pragma unroll
+            for (int i = 0; i < KCH; ++i) xc[i] = xn[i];
+        }
+        __syncthreads();
+    }
+    // the residual is read here, after the k-loop: this kernel's stores are its last instructions
+    if (a.res && a.mode == 0 && live) {
+        const float* resb = a.res + (size_t)b * a.res_bstride;
+        const unsigned vo = (unsigned)(4 * kq) * (unsigned)P + (unsigned)p0;
+#pragma unroll
+        for (int t = 0; t < NCO; ++t)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int cu = 16 * (t0 + t) + r;
+                if (t < tcnt && cu + 4 * kq < a.Cout) {
+                    const float4 rv = ldv(resb + (size_t)cu * P, vo);
+                    acc[t][0][r] += rv.x; acc[t][1][r] += rv.y; acc[t][2][r] += rv.z; acc[t][3][r] += rv.w;
+                }
+            }
+    }
+    epilogue<NCO, false>(a, acc, t0, tcnt, bias_l, nullptr, b, p0, kq, live);
+}
+
+// ---------------------------------------------------------------------------------------------
+// Ragged shapes (P % 4 != 0, unaligned views): one thread per output pixel and channel, plain
+// FMA over K with a two-pass LayerNorm.  Correctness path only (e.g. w = 266 at level 3 of a
+// 1424x2128 frame has P % 4 == 0 and never comes here; tiny odd test frames do).
+// ---------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) conv1x1_scalar_kernel(Conv1x1Args a) {
+    const int P = a.P, K = a.C1 + a.C2, NT = (a.Cout + 15) >> 4;
+    const int b = blockIdx.y;
+    const float* wp = a.wp + (size_t)b * a.wp_bstride;
+    for (int p = blockIdx.x * 256 + threadIdx.x; p < P; p += gridDim.x * 256) {
+        auto xat = [&](int k) {
+            return (k < a.C1) ? a.x1[(size_t)b * a.x1_bstride + (size_t)k * P + p]
+                              : a.x2[(size_t)b * a.x2_bstride + (size_t)(k - a.C1) * P + p];
+        };
+        float mu = 0.f, rstd = 1.f;
+        if (a.ln_w) {
+            for (int k = 0; k < K; ++k) mu += xat(k);
+            mu /= (float)K;
+            float var = 0.f;
+            for (int k = 0; k < K; ++k) { const float d = xat(k) - mu; var = fmaf(d, d, var); }
+            rstd = 1.0f / sqrtf(var / (float)K + a.ln_eps);
+            if (!a.ln_b) mu = 0.f;
+        }
+        for (int co = 0; co < a.Cout; ++co) {
+            float s = 0.f;
+            for (int k = 0; k < K; ++k) {
+                float xv = xat(k);
+                if (a.ln_w) xv = fmaf((xv - mu) * rstd, a.ln_w[k], a.ln_b ? a.ln_b[k] : 0.f);
+                s = fmaf(wp[((size_t)(k >> 2) * NT + (co >> 4)) * 64 + (co & 15) + 16 * (k & 3)], xv, s);
+            }
+            if (a.mode == 0) {
+                s += a.bias ? a.bias[co] : 0.f;
+                if (a.res) s += a.res[(size_t)b * a.res_bstride + (size_t)co * P + p];
+                if (a.act == 1) s = s > 0.f ? s : 0.2f * s;
+                a.out[(size_t)b * a.out_bstride + (size_t)co * P + p] = s;
+            } else {
+                const int o = co >> 2, y = p / a.w, x = p - y * a.w;
+                s += a.bias ? a.bias[o] : 0.f;
+                a.out[(size_t)b * a.out_bstride + (size_t)o * 4 * P + (size_t)(2 * y + ((co >> 1) & 1)) * (2 * a.w) + 2 * x + (co & 1)] = s;
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+template <int KS, int RT>
+static void launch_res_rt(const Conv1x1Args& a, int ntw, int ngroups, int ablate, dim3 grid, size_t lds, hipStream_t st) {
+    constexpr bool DBUF = KS <= 16 && !(KS > 8 && RT == 4);
+    if (a.ln_w) conv1x1_res_kernel<KS, true, RT, DBUF><<<grid, 256, lds, st>>>(a, ntw, ngroups, ablate);
+    else conv1x1_res_kernel<KS, false, RT, DBUF><<<grid, 256, lds, st>>>(a, ntw, ngroups, ablate);
+}
+
+template <int KS>
+static void launch_res(const Conv1x1Args& a, int ntw, int ngroups, int ablate, dim3 grid, size_t lds, hipStream_t st) {
+    if constexpr (KS <= 16) {
+        if (a.res && ntw > 2) launch_res_rt<KS, 4>(a, ntw, ngroups, ablate, grid, lds, st);
+        else if (a.res) launch_res_rt<KS, 2>(a, ntw, ngroups, ablate, grid, lds, st);
+        else launch_res_rt<KS, 0>(a, ntw, ngroups, ablate, grid, lds, st);
+    } else {
+        conv1x1_res_kernel<KS, false, 0, false><<<grid, 256, lds, st>>>(a, ntw, ngroups, ablate);
+    }
+}
+
+int launch_conv1x1(const Conv1x1Args& a, hipStream_t st) {
+    RF_CHECK_ARG(a.B > 0 && a.P > 0 && a.C1 > 0 && a.C2 >= 0 && a.Cout > 0, "conv1x1: bad sizes B=%d P=%d C1=%d C2=%d Cout=%d",
+                 a.B, a.P, a.C1, a.C2, a.Cout);
+    RF_CHECK_ARG(a.C1 % 4 == 0 && a.C2 % 4 == 0, "conv1x1: input channel counts (%d, %d) must be multiples of 4", a.C1, a.C2);
+    RF_CHECK_ARG(a.C2 == 0 || a.x2 != nullptr, "conv1x1: second source missing");
+    RF_CHECK_ARG(a.mode == 0 || (a.Cout % 4 == 0 && a.w > 0 && a.P % a.w == 0 && !a.res), "conv1x1: bad ConvTranspose geometry");
+    RF_CHECK_ARG(a.B <= 65535 && (double)a.P * 4.0 * 16.0 < 4.0e9, "conv1x1: batch %d / plane %d too large", a.B, a.P);
+    const int K = a.C1 + a.C2;
+    const int NS = K / 4, NT = cdiv(a.Cout, 16);
+    bool vec = (a.P % 4 == 0) && aligned16(a.x1) && aligned16(a.out) && (a.x1_bstride % 4 == 0) && (a.out_bstride % 4 == 0);
+    if (a.x2) vec = vec && aligned16(a.x2) && (a.x2_bstride % 4 == 0);
+    if (a.res) vec = vec && aligned16(a.res) && (a.res_bstride % 4 == 0);
+    if (a.mode == 1) vec = vec && (a.w % 4 == 0);
+    int ablate = 0;
+    if (const char* ab = getenv("RF_ABLATE")) ablate = atoi(ab) & 3;   // diagnostic: 1 = no stores, 2 = no x loads
+    const double px = (double)a.B * a.P;
+    const double work_flops = 2.0 * K * a.Cout * px, work_bytes = 4.0 * px * (K + a.Cout + (a.res ? a.Cout : 0));
+    char key[64];
+    if (!vec || (a.res && a.Cout % 16 != 0)) {
+        ProfScope prof(st, "conv1x1_scalar_kernel", work_flops, work_bytes);
+        int gx = cdiv(a.P, 256);
+        if (gx > 4096) gx = 4096;
+        conv1x1_scalar_kernel<<<dim3((unsigned)gx, (unsigned)a.B), 256, 0, st>>>(a);
+    } else if (NS <= 16 || (NS <= 32 && !a.ln_w && !a.res)) {
+        const int ks = NS <= 4 ? 4 : NS <= 8 ? 8 : NS <= 12 ? 12 : NS <= 16 ? 16 : NS <= 24 ? 24 : 32;
+        // output tiles per workgroup: weight slice <= ~60 KB, and <= 8 tiles when the residual rows
+        // are prefetched into registers
+        int cap = (240 / ks) & ~1;
+        if (a.res && cap > 4) cap = 4;
+        int ntw = NT < cap ? NT : cap;
+        const int ngroups = cdiv(NT, ntw);
+        const int tpad = cdiv(ntw, 2) * 2;
+        const size_t lds = ((size_t)ks * tpad * 64 + tpad * 16 + 8 * ks) * sizeof(float);
+        // persistent workgroups: enough to fill every CU at this kernel's occupancy, split over the images
+        const int slots = 256 * (ks <= 8 ? 3 : 2);
+        int wgs = cdiv(slots, a.B * ngroups);
+        if (wgs > cdiv(a.P, 256)) wgs = cdiv(a.P, 256);
+        dim3 grid((unsigned)(wgs * ngroups), (unsigned)a.B, 1);
+        snprintf(key, sizeof(key), "conv1x1_res_kernel<%d, %s, %s>", ks, a.ln_w ? "true" : "false", a.res ? "true" : "false");
+        ProfScope prof(st, key, work_flops, work_bytes);
+        switch (ks) {
+            case 4: launch_res<4>(a, ntw, ngroups, ablate, grid, lds, st); break;
+            case 8: launch_res<8>(a, ntw, ngroups, ablate, grid, lds, st); break;
+            case 12: launch_res<12>(a, ntw, ngroups, ablate, grid, lds, st); break;
+            case 16: launch_res<16>(a, ntw, ngroups, ablate, grid, lds, st); break;
+            case 24: launch_res<24>(a, ntw, ngroups, ablate, grid, lds, st); break;
+            default: launch_res<32>(a, ntw, ngroups, ablate, grid, lds, st); break;
+        }
+    } else {
+        // accumulator tiles per workgroup: 8 (128 channels) unless that would be mostly padding
+        const int nco = (NT % 8 == 0 || NT > 12) ? 8 : 4;
+        const int ngroups = cdiv(NT, nco);
+        dim3 grid((unsigned)(cdiv(a.P, 256) * ngroups), (unsigned)a.B, 1);
+        snprintf(key, sizeof(key), "conv1x1_stream_kernel<%d, %d, %s>", nco, nco == 8 ? 4 : 8, a.ln_w ? "true" : "false");
+        ProfScope prof(st, key, work_flops, work_bytes);
+        if (nco == 8) {
+            if (a.ln_w) conv1x1_stream_kernel<8, 4, true><<<grid, 256, 0, st>>>(a, ngroups);
+            else conv1x1_stream_kernel<8, 4, false><<<grid, 256, 0, st>>>(a, ngroups);
+        } else {
+            if (a.ln_w) conv1x1_stream_kernel<4, 8, true><<<grid, 256, 0, st>>>(a, ngroups);
+            else conv1x1_stream_kernel<4, 8, false><<<grid, 256, 0, st>>>(a, ngroups);
+        }
+    }
+    return check_launch("conv1x1");
+}
+
+}  // namespace rf
