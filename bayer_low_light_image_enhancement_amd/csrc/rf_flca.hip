@@ -157,7 +157,85 @@ int launch_guidance_level(const float* scratch, float* guide, int B, int H, int 
 }
 
 // ------------------------------------------------------------------------------------------
-int flca_nblk(int h, int w) { return cdiv(h * w, 256); }
+// Spatial modulation.  Vector path (w % 4 == 0): a lane owns 4 consecutive pixels of a row and
+// keeps their 3x6 guidance neighbourhoods of all four planes in registers (72 floats); the channel
+// loop prefetches the next channel's feature float4 while the current one is in the VALU;
+// sigmoid / tanh use v_exp_f32 + v_rcp_f32 (about 1 ulp each, far below the parity budget).
+// The 36 weights of a channel are wave-uniform (scalar loads).  Per-block channel sums feed the
+// squeeze-excite pooling without atomics.
+int flca_nblk(int h, int w) { return (w % 4 == 0) ? cdiv(h * w, 1024) : cdiv(h * w, 256); }
+
+__device__ __forceinline__ float fast_sigmoid(float x) { return __builtin_amdgcn_rcpf(1.0f + __expf(-x)); }
+__device__ __forceinline__ float fast_tanh(float x) { return 1.0f - 2.0f * __builtin_amdgcn_rcpf(1.0f + __expf(2.0f * x)); }
+
+__global__ void __launch_bounds__(256) flca_spatial_vec_kernel(FlcaSpatialArgs a, const float* __restrict__ w_low,
+                                                               const float* __restrict__ w_high, const float* __restrict__ w_chr,
+                                                               const float* __restrict__ feat, float* __restrict__ xs) {
+    const int blk = blockIdx.x;
+    const size_t b = blockIdx.y;
+    const int h = a.h, w = a.w, P = h * w, C = a.C;
+    const int p = (blk * 256 + threadIdx.x) * 4;
+    const bool live = p < P;
+    const int y = live ? p / w : 0, x = live ? p - (p / w) * w : 0;
+    float nb[4][3][6];
+    const float* gb = a.guide + b * 4 * (size_t)P;
+#pragma unroll
+    for (int pl = 0; pl < 4; ++pl)
+#pragma unroll
+        for (int dy = 0; dy < 3; ++dy) {
+            const int yy = y + dy - 1;
+            const bool rok = live && yy >= 0 && yy < h;
+            const float* row = gb + (size_t)pl * P + (size_t)(rok ? yy : 0) * w;
+            const float4 m = *reinterpret_cast<const float4*>(row + x);
+            const float l = row[x > 0 ? x - 1 : 0], r = row[x + 4 < w ? x + 4 : 0];
+            nb[pl][dy][0] = (rok && x > 0) ? l : 0.f;
+            nb[pl][dy][1] = rok ? m.x : 0.f; nb[pl][dy][2] = rok ? m.y : 0.f;
+            nb[pl][dy][3] = rok ? m.z : 0.f; nb[pl][dy][4] = rok ? m.w : 0.f;
+            nb[pl][dy][5] = (rok && x + 4 < w) ? r : 0.f;
+        }
+    const float al = *a.alpha, be = *a.beta, ga = *a.gamma;
+    __shared__ float red[512][4];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const float* fb = feat + b * (size_t)C * P + (live ? p : 0);
+    float* xb = xs + b * (size_t)C * P + p;
+    float4 fcur = *reinterpret_cast<const float4*>(fb);
+    for (int c = 0; c < C; ++c) {
+        const float4 fnext = *reinterpret_cast<const float4*>(fb + (size_t)(c + 1 < C ? c + 1 : c) * P);
+        const float* wl = w_low + c * 9;
+        const float* wh = w_high + c * 9;
+        const float* wc = w_chr + c * 18;
+        float sl[4] = {0.f, 0.f, 0.f, 0.f}, sh[4] = {0.f, 0.f, 0.f, 0.f}, sc[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int dy = 0; dy < 3; ++dy)
+#pragma unroll
+            for (int dx = 0; dx < 3; ++dx) {
+                const float k0 = wl[dy * 3 + dx], k1 = wh[dy * 3 + dx], k2 = wc[dy * 3 + dx], k3 = wc[9 + dy * 3 + dx];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    sl[q] = fmaf(k0, nb[0][dy][q + dx], sl[q]);
+                    sh[q] = fmaf(k1, nb[1][dy][q + dx], sh[q]);
+                    sc[q] = fmaf(k3, nb[3][dy][q + dx], fmaf(k2, nb[2][dy][q + dx], sc[q]));
+                }
+            }
+        float v[4];
+        const float fv[4] = {fcur.x, fcur.y, fcur.z, fcur.w};
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+            v[q] = fv[q] * (1.0f + al * fast_sigmoid(sl[q]) + be * fast_tanh(sh[q]) + ga * fast_sigmoid(sc[q]));
+        float s = 0.f;
+        if (live) {
+            *reinterpret_cast<float4*>(xb + (size_t)c * P) = make_float4(v[0], v[1], v[2], v[3]);
+            s = (v[0] + v[1]) + (v[2] + v[3]);
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+        if (lane == 0) red[c][wave] = s;
+        fcur = fnext;
+    }
+    __syncthreads();
+    for (int c = threadIdx.x; c < C; c += 256)
+        a.partial[(b * a.nblk + blk) * C + c] = (red[c][0] + red[c][1]) + (red[c][2] + red[c][3]);
+}
 
 __global__ void __launch_bounds__(256) flca_spatial_kernel(FlcaSpatialArgs a) {
     const int blk = blockIdx.x;
@@ -192,17 +270,11 @@ __global__ void __launch_bounds__(256) flca_spatial_kernel(FlcaSpatialArgs a) {
         for (int t = 0; t < 9; ++t) {
             sl = fmaf(wl[t], nb[0][t], sl);
             sh = fmaf(wh[t], nb[1][t], sh);
-            sc = fmaf(wc[t], nb[2][t], sc);
+            sc = fmaf(wc[9 + t], nb[3][t], fmaf(wc[t], nb[2][t], sc));
         }
-#pragma unroll
-        for (int t = 0; t < 9; ++t) sc = fmaf(wc[9 + t], nb[3][t], sc);
-        const float a_low = 1.0f / (1.0f + expf(-sl));
-        const float a_high = tanhf(sh);
-        const float a_chr = 1.0f / (1.0f + expf(-sc));
-        const float spatial = 1.0f + al * a_low + be * a_high + ga * a_chr;
         float v = 0.f;
         if (live) {
-            v = fb[(size_t)c * P + p] * spatial;
+            v = fb[(size_t)c * P + p] * (1.0f + al * fast_sigmoid(sl) + be * fast_tanh(sh) + ga * fast_sigmoid(sc));
             xb[(size_t)c * P + p] = v;
         }
 #pragma unroll
@@ -216,9 +288,15 @@ __global__ void __launch_bounds__(256) flca_spatial_kernel(FlcaSpatialArgs a) {
 
 int launch_flca_spatial(const FlcaSpatialArgs& a, hipStream_t st) {
     RF_CHECK_ARG(a.C <= 512 && a.B <= 65535, "flca: C=%d > 512 not supported", a.C);
+    RF_CHECK_ARG(a.nblk == flca_nblk(a.h, a.w), "flca: partial-sum block count mismatch");
     const double el = (double)a.B * a.C * a.h * a.w;
-    ProfScope prof(st, "flca_spatial_kernel", 80.0 * el, 8.0 * el);
-    flca_spatial_kernel<<<dim3((unsigned)a.nblk, (unsigned)a.B), 256, 0, st>>>(a);
+    const bool vec = (a.w % 4 == 0) && aligned16(a.feat) && aligned16(a.xs) && aligned16(a.guide);
+    RF_CHECK_ARG(vec || a.w % 4 != 0, "flca: feature / guidance buffers must be 16-byte aligned");
+    ProfScope prof(st, vec ? "flca_spatial_vec_kernel" : "flca_spatial_kernel", 80.0 * el, 8.0 * el);
+    if (vec)
+        flca_spatial_vec_kernel<<<dim3((unsigned)a.nblk, (unsigned)a.B), 256, 0, st>>>(a, a.w_low, a.w_high, a.w_chr, a.feat, a.xs);
+    else
+        flca_spatial_kernel<<<dim3((unsigned)a.nblk, (unsigned)a.B), 256, 0, st>>>(a);
     return check_launch("flca_spatial");
 }
 

@@ -1,0 +1,126 @@
+"""Image-parallel inference: batch sharding and full-frame tiling across ranks.
+
+The reference has no tiling or multi-GPU inference at all (test.py:72 runs whole frames with
+batch_size=1; training uses nn.DataParallel, train.py:108-111).  RawFormer is per-image
+everywhere (attention, squeeze-excite and the luma maximum reduce over ONE image), so
+
+* a batch shards across ranks with no communication (``shard_batch``), and
+* a full frame can be cut into overlapping tiles that are each an independent "image"
+  (``plan_tiles`` / ``forward_tiled``).  Independent tiles change the per-image statistics, so
+  the parity oracle for tiled mode is *the same forward run on the same tiles*
+  (SURVEY.md section 8e), not the whole-frame forward.
+
+``forward_full_frame_sharded`` runs rank r's tiles on rank r and stitches the sRGB frame on
+every rank with ONE all-gather of fixed-size tile outputs (RCCL over xGMI with the ``nccl``
+backend; ``gloo`` in the CPU tests).  Nothing here touches the HIP library: the per-tile
+forward is any callable ``[b,1,h,w] -> [b,3,h,w]`` (normally ``RawFormer.forward``).
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass
+from typing import Callable, List, Sequence, Tuple
+
+import torch
+
+ALIGN = 16  # mosaic sizes must be multiples of 16 (Bayer pack + three 2x down-samplings)
+
+
+@dataclass(frozen=True)
+class Tile:
+    """A tile in MOSAIC coordinates.  ``src`` is what the model sees (multiple of 16, inside the
+    frame), ``dst`` the part of the frame it is responsible for, ``crop`` = dst relative to src."""
+    src: Tuple[int, int, int, int]   # y0, x0, h, w
+    dst: Tuple[int, int, int, int]
+    crop: Tuple[int, int, int, int]
+
+
+def _cuts(n: int, parts: int) -> List[int]:
+    """Frame split points on even (Bayer-phase preserving) coordinates."""
+    pts = [int(round(i * n / parts / 2.0)) * 2 for i in range(parts + 1)]
+    pts[0], pts[-1] = 0, n
+    return pts
+
+
+def _span(lo: int, hi: int, n: int, overlap: int) -> Tuple[int, int]:
+    """Source interval covering [lo, hi) plus ``overlap`` on each side, length a multiple of
+    ALIGN, start even, clipped to [0, n)."""
+    a = max(0, lo - overlap)
+    a -= a % 2
+    b = min(n, hi + overlap)
+    length = -(-(b - a) // ALIGN) * ALIGN
+    if length > n:
+        raise ValueError(f"frame side {n} is not a multiple of {ALIGN} and too small to tile")
+    if a + length > n:            # grow to the left instead of past the border
+        a = n - length
+        a -= a % 2
+    return a, length
+
+
+def plan_tiles(height: int, width: int, grid: Tuple[int, int], overlap: int = 32) -> List[Tile]:
+    """Cut a ``height x width`` mosaic into ``grid = (rows, cols)`` tiles with ``overlap`` mosaic
+    pixels of context on interior edges.  Works for sizes such as 2848x4256 (SID Sony) whose
+    eighth/sixteenth parts are not integers: tile sources are grown to a multiple of 16."""
+    if height % 2 or width % 2:
+        raise ValueError("mosaic size must be even")
+    ys, xs = _cuts(height, grid[0]), _cuts(width, grid[1])
+    tiles = []
+    for i in range(grid[0]):
+        for j in range(grid[1]):
+            y0, hh = _span(ys[i], ys[i + 1], height, overlap)
+            x0, ww = _span(xs[j], xs[j + 1], width, overlap)
+            dst = (ys[i], xs[j], ys[i + 1] - ys[i], xs[j + 1] - xs[j])
+            tiles.append(Tile((y0, x0, hh, ww), dst, (dst[0] - y0, dst[1] - x0, dst[2], dst[3])))
+    return tiles
+
+
+def shard_batch(n_items: int, rank: int, world: int) -> range:
+    """Contiguous, balanced share of ``n_items`` images for ``rank`` (may be empty)."""
+    base, extra = divmod(n_items, world)
+    start = rank * base + min(rank, extra)
+    return range(start, start + base + (1 if rank < extra else 0))
+
+
+def forward_tiled(forward: Callable[[torch.Tensor], torch.Tensor], x: torch.Tensor, tiles: Sequence[Tile],
+                  out_channels: int = 3) -> torch.Tensor:
+    """Single-process tiled forward: every tile is an independent image."""
+    b, _, h, w = x.shape
+    out = x.new_empty((b, out_channels, h, w))
+    for t in tiles:
+        y0, x0, hh, ww = t.src
+        o = forward(x[:, :, y0:y0 + hh, x0:x0 + ww].contiguous())
+        cy, cx, ch, cw = t.crop
+        out[:, :, t.dst[0]:t.dst[0] + ch, t.dst[1]:t.dst[1] + cw] = o[:, :, cy:cy + ch, cx:cx + cw]
+    return out
+
+
+def forward_full_frame_sharded(forward: Callable[[torch.Tensor], torch.Tensor], x: torch.Tensor,
+                               tiles: Sequence[Tile], group=None, out_channels: int = 3) -> torch.Tensor:
+    """Tile-parallel full-frame forward.  Every rank holds the whole mosaic ``x`` (it is 1/3 the
+    size of the output), runs tiles ``rank, rank + world, ...`` and receives all tile outputs with
+    one all-gather; the stitched frame is returned on every rank.
+
+    Tile outputs are padded to the largest tile so the collective has a fixed shape
+    (config 4: 8 tiles of 3 x ~1.5k x ~1.1k fp32, about 18 MB per rank).
+    """
+    import torch.distributed as dist
+
+    world = dist.get_world_size(group)
+    rank = dist.get_rank(group)
+    b, _, h, w = x.shape
+    per_rank = -(-len(tiles) // world)
+    mh = max(t.src[2] for t in tiles)
+    mw = max(t.src[3] for t in tiles)
+    mine = x.new_zeros((per_rank, b, out_channels, mh, mw))
+    for slot in range(per_rank):
+        idx = rank + slot * world
+        if idx < len(tiles):
+            y0, x0, hh, ww = tiles[idx].src
+            mine[slot, :, :, :hh, :ww] = forward(x[:, :, y0:y0 + hh, x0:x0 + ww].contiguous())
+    gathered = x.new_empty((world,) + tuple(mine.shape))
+    dist.all_gather_into_tensor(gathered.view(world * per_rank, b, out_channels, mh, mw), mine, group=group)
+    out = x.new_empty((b, out_channels, h, w))
+    for idx, t in enumerate(tiles):
+        r, slot = idx % world, idx // world
+        cy, cx, ch, cw = t.crop
+        out[:, :, t.dst[0]:t.dst[0] + ch, t.dst[1]:t.dst[1] + cw] = gathered[r, slot, :, :, cy:cy + ch, cx:cx + cw]
+    return out

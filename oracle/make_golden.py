@@ -285,16 +285,35 @@ def whole_model(flca_mod, big):
              in_checksum=checksum(x))
 
 
+def state_dict_keys(flca_mod):
+    """Key names and shapes of the reference's state_dict (what test.py:88-91 loads strictly)."""
+    import json
+    out = {}
+    for dim in (32, 48, 64):
+        m = flca_mod.RawFormer(dim=dim)
+        out[str(dim)] = [[k, list(v.shape)] for k, v in m.state_dict().items()]
+    path = os.path.join(GOLD, "state_dict_keys.json")
+    with open(path, "w") as f:
+        json.dump(out, f)
+    log(f"  wrote {os.path.relpath(path, REPO)} ({os.path.getsize(path)} B)")
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--big", action="store_true", help="also run BASELINE configs 2-3 (minutes of CPU)")
+    ap.add_argument("--only-keys", action="store_true", help="only (re)write state_dict_keys.json")
     args = ap.parse_args()
+    if args.only_keys:
+        os.makedirs(GOLD, exist_ok=True)
+        state_dict_keys(import_reference()[0])
+        return
     os.makedirs(GOLD, exist_ok=True)
     torch.manual_seed(0)
     torch.set_num_threads(8)
     mods = import_reference()
     per_op(*mods)
     whole_model(mods[0], args.big)
+    state_dict_keys(mods[0])
     with open(os.path.join(GOLD, "PINNING.txt"), "w") as f:
         f.write("# written by oracle/make_golden.py: reference (run on CPU here) vs oracle/rawformer_ref.py\n")
         f.write("\n".join(LOG) + "\n")
