@@ -92,4 +92,5 @@ def test_two_rank_tiled_and_batch_sharded_inference(tmp_path):
     # torch CPU convolutions round differently for different batch sizes / thread counts
     assert np.abs(got["batch"] - ref_batch.numpy()).max() <= 2e-5
     # tiles are independent images: close to, but not identical with, the whole-frame forward
-    assert 1e-6 < np.abs(got["tiled"] - whole.numpy()).max() < 1.0
+    d = np.abs(got["tiled"] - whole.numpy())
+    assert d.max() > 1e-6 and d.mean() < 0.1
