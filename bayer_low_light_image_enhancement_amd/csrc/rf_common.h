@@ -134,6 +134,15 @@ int launch_gram(const GramArgs& a, hipStream_t st);
 int launch_attn_fold(const float* partial, int nslab, const float* temperature, const float* w_out,
                      float* wp_out, int B, int C, int heads, hipStream_t st);
 
+// ---- fused transformer-block kernels for C = 32 / 64 (rf_fused.hip)
+bool fused_ffn_supported(int C, int hidden, int h, int w);
+int launch_ffn_fused(const float* x, float* out, const float* ln_w, const float* ln_b, const float* w1p, const float* b1,
+                     const float* wd, const float* bd, const float* w2p, const float* b2, int B, int C, int h, int w, hipStream_t st);
+bool fused_attn_supported(int C, int heads, int h, int w);
+int fused_attn_plan(int h, int w, int* nslab, size_t* partial_floats, int B, int C);
+int launch_attn_front(const float* x, float* v, float* partial, int nslab, const float* ln_w, const float* ln_b,
+                      const float* wp, const float* bq, const float* wd, const float* bd, int B, int C, int h, int w, hipStream_t st);
+
 // ---- FLCA (rf_flca.hip)
 size_t guidance_scratch_floats(int B, int H, int W);
 // packed-or-mosaic input -> base planes in scratch (y, cr, cb at HxW; LL, mag at H/2 x W/2)

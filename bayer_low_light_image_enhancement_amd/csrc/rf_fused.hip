@@ -1,0 +1,467 @@
+// Fused transformer-block kernels for the HBM-bound U-Net levels (C = 32 or 64 channels).
+//
+// Un-fused, one TransformerBlock moves ~26 C floats per pixel through HBM (qkv 1x1: C in / 3C out,
+// depthwise 3x3: 3C/3C, Gram: 2C, ...; ffn: C/2C, 2C/2C, 2C+C/C).  Here the wide intermediates
+// (qkv before/after the depthwise conv, the FFN hidden tensor) never leave the CU:
+//
+//   ffn_fused_kernel    x1 -> LN2 -> 1x1 (C->2C) -> dw3x3 -> GELU -> 1x1 (2C->C) + x1      reads C, writes C
+//   attn_front_kernel   x  -> LN1 -> 1x1 (C->3C) -> dw3x3 -> { Gram partials of q,k ; v }   reads C, writes C
+//
+// Tile = 4 rows x 64 px per workgroup (4 waves, one output row each) plus a 1-pixel halo, held as
+// 6 rows x 72 columns (columns x0-4 .. x0+67, so every 4-pixel group is 16-byte aligned in HBM and
+// either wholly inside or wholly outside the image).
+//   Phase A (per part of 32 intermediate channels): each wave owns 27 of the 108 halo'd pixel
+//     groups as two MFMA steps; its LayerNorm'd input (C x 64 px per step) stays in registers for
+//     all parts (the resident-input GEMM of rf_gemm1x1.hip), D tiles go to LDS (+bias, zero outside
+//     the image: the depthwise conv pads ITS input, i.e. the 1x1 output).
+//   Phase B: a lane reads the 3x6 neighbourhood of its 4 pixels from LDS, runs the 9-tap stencil
+//     in registers and feeds the result straight into the next MFMA as B operand (FFN: second 1x1;
+//     attention: q k^T, q q^T, k k^T with the pixel axis as K) or stores it (v).
+// Weights of the current part are staged in LDS in MFMA lane order.  All cross-workgroup
+// reductions go through fixed-order partials (bitwise reproducible).
+#include <cstdio>
+#include "rf_common.h"
+
+namespace rf {
+
+namespace fused {
+constexpr int TH = 4, TW = 64;          // output tile
+constexpr int HR = TH + 2;              // halo'd rows
+constexpr int HC = 72;                  // halo'd columns held (18 groups of 4 px)
+constexpr int NG = HR * (HC / 4);       // 108 pixel groups per tile
+constexpr int GPW = NG / 4;             // 27 groups per wave in phase A (two MFMA steps: 16 + 11)
+constexpr int PART = 32;                // intermediate channels per part
+}  // namespace fused
+
+// erf by Abramowitz-Stegun 7.1.26 (|error| <= 1.5e-7): one v_exp, one v_rcp, 6 fma
+__device__ __forceinline__ float gelu_fast(float v) {
+    const float x = fabsf(v) * 0.70710678118654752440f;
+    const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, x, 1.0f));
+    float p = fmaf(1.061405429f, t, -1.453152027f);
+    p = fmaf(p, t, 1.421413741f);
+    p = fmaf(p, t, -0.284496736f);
+    p = fmaf(p, t, 0.254829592f);
+    const float e = 1.0f - p * t * __expf(-x * x);       // erf(|v| / sqrt 2)
+    return 0.5f * v * (1.0f + copysignf(e, v));
+}
+
+// ---- shared phase-A machinery ------------------------------------------------------------------
+// The wave's two steps of halo'd pixel groups: geometry of step st for lane j.
+struct GroupGeom {
+    int lds_off;     // row * HC + 4 * cg
+    int goff;        // y * w + x  (clamped to 0 when outside)
+    bool valid;
+};
+__device__ __forceinline__ GroupGeom group_geom(int wave, int st, int j, int y0, int x0, int h, int w) {
+    using namespace fused;
+    GroupGeom g;
+    const int gi = wave * GPW + st * 16 + j;
+    const bool in_step = (st == 0) || (j < GPW - 16);
+    const int row = gi / (HC / 4), cg = gi % (HC / 4);
+    const int y = y0 - 1 + row, x = x0 - 4 + 4 * cg;
+    g.valid = in_step && y >= 0 && y < h && x >= 0 && x < w;
+    g.lds_off = in_step ? row * HC + 4 * cg : -1;
+    g.goff = g.valid ? y * w + x : 0;
+    return g;
+}
+
+// Load and LayerNorm the wave's input tile for one step: xh[s] = LN(x)[channel 4s + kq][4 px].
+template <int C>
+__device__ __forceinline__ void load_ln_step(const float* __restrict__ xb, int P, int kq, const GroupGeom& g,
+                                             const float* __restrict__ gam_l, const float* __restrict__ bet_l,
+                                             float eps, float4 (&xh)[C / 4]) {
+    constexpr int NS = C / 4;
+    const unsigned voff = (unsigned)kq * (unsigned)P + (unsigned)g.goff;
+#pragma unroll
+    for (int s = 0; s < NS; ++s) xh[s] = *reinterpret_cast<const float4*>(xb + (size_t)(4 * s) * P + voff);
+    float sum[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int s = 0; s < NS; ++s) { sum[0] += xh[s].x; sum[1] += xh[s].y; sum[2] += xh[s].z; sum[3] += xh[s].w; }
+    float mu[4], var[4] = {0.f, 0.f, 0.f, 0.f}, rstd[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        sum[q] += __shfl_xor(sum[q], 16);
+        sum[q] += __shfl_xor(sum[q], 32);
+        mu[q] = sum[q] * (1.0f / C);
+    }
+#pragma unroll
+    for (int s = 0; s < NS; ++s) {
+        const float d0 = xh[s].x - mu[0], d1 = xh[s].y - mu[1], d2 = xh[s].z - mu[2], d3 = xh[s].w - mu[3];
+        var[0] = fmaf(d0, d0, var[0]); var[1] = fmaf(d1, d1, var[1]);
+        var[2] = fmaf(d2, d2, var[2]); var[3] = fmaf(d3, d3, var[3]);
+    }
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        var[q] += __shfl_xor(var[q], 16);
+        var[q] += __shfl_xor(var[q], 32);
+        rstd[q] = 1.0f / sqrtf(var[q] * (1.0f / C) + eps);
+    }
+#pragma unroll
+    for (int s = 0; s < NS; ++s) {
+        const float gk = gam_l[4 * s + kq], bk = bet_l[4 * s + kq];
+        xh[s].x = fmaf((xh[s].x - mu[0]) * rstd[0], gk, bk);
+        xh[s].y = fmaf((xh[s].y - mu[1]) * rstd[1], gk, bk);
+        xh[s].z = fmaf((xh[s].z - mu[2]) * rstd[2], gk, bk);
+        xh[s].w = fmaf((xh[s].w - mu[3]) * rstd[3], gk, bk);
+    }
+}
+
+// One phase-A step: 2 output tiles (32 intermediate channels) of the 1x1 GEMM, written to the LDS
+// plane array `mid` (plane stride PS) with bias; groups outside the image are written as zeros.
+template <int C, int WT>
+__device__ __forceinline__ void phase_a_step(const float4 (&xh)[C / 4], const float* __restrict__ wl /* [C/4][WT][64] + lane */,
+                                             int tile0, int tile1, const float* __restrict__ bias0, const float* __restrict__ bias1,
+                                             float* __restrict__ mid, int PS, int kq, const GroupGeom& g) {
+    f32x4 acc[2][4];
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) acc[t][q] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    const float* w0 = wl + tile0 * 64;
+    const float* w1 = wl + tile1 * 64;
+#pragma unroll
+    for (int s = 0; s < C / 4; ++s) {
+        const float xb[4] = {xh[s].x, xh[s].y, xh[s].z, xh[s].w};
+        const float a0 = w0[s * WT * 64], a1 = w1[s * WT * 64];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) acc[0][q] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, xb[q], acc[0][q], 0, 0, 0);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) acc[1][q] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1, xb[q], acc[1][q], 0, 0, 0);
+    }
+    if (g.lds_off >= 0) {
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float bs = (t ? bias1 : bias0)[4 * kq + r];
+                float4 v = make_float4(acc[t][0][r] + bs, acc[t][1][r] + bs, acc[t][2][r] + bs, acc[t][3][r] + bs);
+                if (!g.valid) v = make_float4(0.f, 0.f, 0.f, 0.f);
+                *reinterpret_cast<float4*>(mid + (16 * t + 4 * kq + r) * PS + g.lds_off) = v;
+            }
+    }
+}
+
+// 3x3 depthwise stencil for 4 consecutive pixels from an LDS plane: `p` points at the plane's
+// (row of the output pixel - 1, column of the first pixel), 16-byte aligned.  The two edge taps of
+// every row must not be scalar LDS reads (lanes 4 floats apart are a 4-way bank conflict on
+// ds_read_b32: measured 58 % of all LDS cycles), so:
+//   stencil4_dpp   lanes j-1 / j+1 of the same 16-lane row hold the neighbouring 4-pixel groups:
+//                  edges come over DPP row shifts; only lanes 0 and 15 read their outer tap.
+//   stencil4_wide  neighbouring groups are not in this wave's registers: three aligned
+//                  ds_read_b128 per row (conflict-free with the plane stride used there).
+__device__ __forceinline__ float dpp_row_shr1(float keep, float v) {   // lane i <- lane i-1 (i % 16 == 0 keeps `keep`)
+    return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(keep), __float_as_int(v), 0x111, 0xf, 0xf, false));
+}
+__device__ __forceinline__ float dpp_row_shl1(float keep, float v) {   // lane i <- lane i+1 (i % 16 == 15 keeps `keep`)
+    return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(keep), __float_as_int(v), 0x101, 0xf, 0xf, false));
+}
+
+__device__ __forceinline__ void stencil4_dpp(const float* __restrict__ p, int j, const float* __restrict__ k9, float bias, float (&out)[4]) {
+    using namespace fused;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) out[q] = bias;
+#pragma unroll
+    for (int dy = 0; dy < 3; ++dy) {
+        const float* row = p + dy * HC;
+        const float4 m = *reinterpret_cast<const float4*>(row);
+        float el = 0.f, er = 0.f;
+        if (j == 0) el = row[-1];
+        if (j == 15) er = row[4];
+        const float v[6] = {dpp_row_shr1(el, m.w), m.x, m.y, m.z, m.w, dpp_row_shl1(er, m.x)};
+        const float k0 = k9[dy * 3], k1 = k9[dy * 3 + 1], k2 = k9[dy * 3 + 2];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) out[q] = fmaf(k2, v[q + 2], fmaf(k1, v[q + 1], fmaf(k0, v[q], out[q])));
+    }
+}
+
+__device__ __forceinline__ void stencil4_wide(const float* __restrict__ p, const float* __restrict__ k9, float bias, float (&out)[4]) {
+    using namespace fused;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) out[q] = bias;
+#pragma unroll
+    for (int dy = 0; dy < 3; ++dy) {
+        const float* row = p + dy * HC;
+        const float4 lft = *reinterpret_cast<const float4*>(row - 4);
+        const float4 m = *reinterpret_cast<const float4*>(row);
+        const float4 rgt = *reinterpret_cast<const float4*>(row + 4);
+        const float v[6] = {lft.w, m.x, m.y, m.z, m.w, rgt.x};
+        const float k0 = k9[dy * 3], k1 = k9[dy * 3 + 1], k2 = k9[dy * 3 + 2];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) out[q] = fmaf(k2, v[q + 2], fmaf(k1, v[q + 1], fmaf(k0, v[q], out[q])));
+    }
+}
+
+// ================================================================================================
+// FFN:  out = x1 + W2 gelu(dw3x3(W1 LN2(x1) + b1) + bd) + b2
+// ================================================================================================
+struct FfnArgs {
+    const float* x;        // [B][C][h][w] block input (also the residual)
+    float* out;            // [B][C][h][w]
+    const float* ln_w; const float* ln_b;
+    const float* w1p;      // packed [C/4][2C/16][64]
+    const float* b1;       // [2C]
+    const float* wd;       // [2C][9]
+    const float* bd;       // [2C]
+    const float* w2p;      // packed [2C/4][C/16][64]
+    const float* b2;       // [C]
+    int B, h, w, tiles_x, ntiles;
+};
+
+template <int C>
+__global__ void __launch_bounds__(256, 2) ffn_fused_kernel(FfnArgs a) {
+    using namespace fused;
+    constexpr int NS = C / 4;            // k-sets of the first GEMM
+    constexpr int NT1 = 2 * C / 16;      // output tiles of the first GEMM (hidden)
+    constexpr int NTO = C / 16;          // output tiles of the second GEMM
+    constexpr int NPART = 2 * C / PART;  // parts of 32 hidden channels
+    constexpr int PS = 448;              // LDS plane stride (multiple of 64: kq planes on disjoint slots)
+    // all weights live in LDS for the lifetime of the (persistent) workgroup
+    __shared__ __attribute__((aligned(16))) float mid[PART * PS + 8];
+    __shared__ __attribute__((aligned(16))) float w1_l[NS * NT1 * 64];
+    __shared__ __attribute__((aligned(16))) float w2_l[(2 * C / 4) * NTO * 64];
+    __shared__ float wd_l[2 * C * 9], bd_l[2 * C], b1_l[2 * C], b2_l[C], gam_l[C], bet_l[C];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int j = lane & 15, kq = lane >> 4;
+    const int b = blockIdx.y;
+    const int h = a.h, w = a.w, P = h * w;
+    const float* xb = a.x + (size_t)b * C * P;
+    float* ob = a.out + (size_t)b * C * P;
+
+    for (int i = tid; i < NS * NT1 * 16; i += 256) *reinterpret_cast<float4*>(w1_l + i * 4) = *reinterpret_cast<const float4*>(a.w1p + i * 4);
+    for (int i = tid; i < (2 * C / 4) * NTO * 16; i += 256) *reinterpret_cast<float4*>(w2_l + i * 4) = *reinterpret_cast<const float4*>(a.w2p + i * 4);
+    for (int i = tid; i < 2 * C * 9; i += 256) wd_l[i] = a.wd[i];
+    for (int i = tid; i < 2 * C; i += 256) { bd_l[i] = a.bd[i]; b1_l[i] = a.b1[i]; }
+    for (int i = tid; i < C; i += 256) { gam_l[i] = a.ln_w[i]; bet_l[i] = a.ln_b[i]; b2_l[i] = a.b2[i]; }
+    __syncthreads();
+
+    for (int tile = blockIdx.x; tile < a.ntiles; tile += gridDim.x) {
+        const int tx = tile % a.tiles_x, ty = tile / a.tiles_x;
+        const int x0 = tx * TW, y0 = ty * TH;
+        // input tile: two steps of LayerNorm'd activations stay in registers for all parts
+        const GroupGeom g0 = group_geom(wave, 0, j, y0, x0, h, w), g1 = group_geom(wave, 1, j, y0, x0, h, w);
+        float4 xh0[NS], xh1[NS];
+        load_ln_step<C>(xb, P, kq, g0, gam_l, bet_l, 1e-5f, xh0);
+        load_ln_step<C>(xb, P, kq, g1, gam_l, bet_l, 1e-5f, xh1);
+
+        const int yo = y0 + wave, xo = x0 + 4 * j;          // this lane's 4 output pixels
+        const bool live = yo < h && xo < w;
+        f32x4 acc[NTO][4];
+#pragma unroll
+        for (int t = 0; t < NTO; ++t)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) acc[t][q] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+#pragma unroll
+        for (int part = 0; part < NPART; ++part) {
+            __syncthreads();                                 // previous phase B is done with mid
+            // ---- phase A: hidden[32 of part][halo tile] = W1 x^ + b1 -> LDS
+            phase_a_step<C, NT1>(xh0, w1_l + lane, 2 * part, 2 * part + 1, b1_l + part * PART, b1_l + part * PART + 16, mid, PS, kq, g0);
+            phase_a_step<C, NT1>(xh1, w1_l + lane, 2 * part, 2 * part + 1, b1_l + part * PART, b1_l + part * PART + 16, mid, PS, kq, g1);
+            __syncthreads();
+            // ---- phase B: depthwise 3x3 + GELU in registers, straight into the second GEMM
+#pragma unroll
+            for (int s = 0; s < PART / 4; ++s) {
+                const int hc = 4 * s + kq;
+                float v[4];
+                stencil4_dpp(mid + hc * PS + wave * HC + 4 * j + 4, j, wd_l + (part * PART + hc) * 9, bd_l[part * PART + hc], v);
+#pragma unroll
+                for (int q = 0; q < 4; ++q) v[q] = gelu_fast(v[q]);
+#pragma unroll
+                for (int t = 0; t < NTO; ++t) {
+                    const float av = w2_l[((part * (PART / 4) + s) * NTO + t) * 64 + lane];
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) acc[t][q] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, v[q], acc[t][q], 0, 0, 0);
+                }
+            }
+        }
+        // ---- epilogue: + b2 + residual
+        if (live) {
+            const unsigned voff = (unsigned)(4 * kq) * (unsigned)P + (unsigned)(yo * w + xo);
+#pragma unroll
+            for (int t = 0; t < NTO; ++t)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int cu = 16 * t + r;
+                    const float bs = b2_l[cu + 4 * kq];
+                    const float4 rv = *reinterpret_cast<const float4*>(xb + (size_t)cu * P + voff);
+                    *reinterpret_cast<float4*>(ob + (size_t)cu * P + voff) =
+                        make_float4(acc[t][0][r] + bs + rv.x, acc[t][1][r] + bs + rv.y, acc[t][2][r] + bs + rv.z, acc[t][3][r] + bs + rv.w);
+                }
+        }
+    }
+}
+
+bool fused_ffn_supported(int C, int hidden, int h, int w) {
+    return C == 32 && hidden == 2 * C && (w % 4 == 0) && ((double)C * h * w * 4.0 < 4.0e9);
+}
+
+int launch_ffn_fused(const float* x, float* out, const float* ln_w, const float* ln_b, const float* w1p, const float* b1,
+                     const float* wd, const float* bd, const float* w2p, const float* b2, int B, int C, int h, int w, hipStream_t st) {
+    RF_CHECK_ARG(fused_ffn_supported(C, 2 * C, h, w) && B <= 65535, "ffn_fused: unsupported shape C=%d %dx%d", C, h, w);
+    RF_CHECK_ARG(aligned16(x) && aligned16(out), "ffn_fused: buffers must be 16-byte aligned");
+    FfnArgs a{x, out, ln_w, ln_b, w1p, b1, wd, bd, w2p, b2, B, h, w, cdiv(w, fused::TW), 0};
+    a.ntiles = a.tiles_x * cdiv(h, fused::TH);
+    int wgs = cdiv(512, B);                       // persistent: two workgroups per CU over the whole batch
+    if (wgs > a.ntiles) wgs = a.ntiles;
+    const dim3 grid((unsigned)wgs, (unsigned)B);
+    const double px = (double)B * h * w;
+    ProfScope prof(st, C == 32 ? "ffn_fused_kernel<32>" : "ffn_fused_kernel<64>", px * (8.0 * C * C + 36.0 * C), px * 8.0 * C);
+    if (C == 32) ffn_fused_kernel<32><<<grid, 256, 0, st>>>(a);
+    else ffn_fused_kernel<64><<<grid, 256, 0, st>>>(a);
+    return check_launch("ffn_fused");
+}
+
+// ================================================================================================
+// Attention front:  qkv = dw3x3(Wqkv LN1(x) + b);  Gram partials of (q, k) per head;  v -> HBM
+// ================================================================================================
+struct AttnFrontArgs {
+    const float* x;        // [B][C][h][w]
+    float* v;              // [B][C][h][w]  depthwise-convolved v
+    float* partial;        // [B][nslab][C/16][16][66]  (layout of rf_attn.hip: band of one k tile)
+    const float* ln_w; const float* ln_b;
+    const float* wp;       // packed qkv weight [C/4][3C/16][64]
+    const float* bq;       // [3C]
+    const float* wd;       // [3C][9]
+    const float* bd;       // [3C]
+    int B, h, w, tiles_x, ntiles, nslab;
+};
+
+template <int C>
+__global__ void __launch_bounds__(256, 2) attn_front_kernel(AttnFrontArgs a) {
+    using namespace fused;
+    constexpr int NS = C / 4;
+    constexpr int NQT = C / 16;          // q (and k) tiles = Gram rounds
+    constexpr int NVP = C / PART;        // v parts
+    constexpr int NT3 = 3 * C / 16;      // tiles of the qkv weight
+    constexpr int PSG = 452;             // plane stride for the Gram rounds: channel planes on shifted slots
+    constexpr int PSV = 448;             // plane stride for the v parts: lanes run along pixels
+    constexpr int ROWW = 4 * 16 + 2;     // partial row width of rf_attn.hip (kMaxBand * 16 + 2)
+    __shared__ __attribute__((aligned(16))) float mid[PART * PSG + 8];
+    __shared__ __attribute__((aligned(16))) float w_l[NS * NT3 * 64];     // whole qkv weight, resident
+    __shared__ float wd_l[3 * C * 9], bd_l[3 * C], bq_l[3 * C], gam_l[C], bet_l[C];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int j = lane & 15, kq = lane >> 4;
+    const int slab = blockIdx.x, b = blockIdx.y;
+    const int h = a.h, w = a.w, P = h * w;
+    const float* xb = a.x + (size_t)b * C * P;
+    float* vb = a.v + (size_t)b * C * P;
+
+    for (int i = tid; i < NS * NT3 * 16; i += 256) *reinterpret_cast<float4*>(w_l + i * 4) = *reinterpret_cast<const float4*>(a.wp + i * 4);
+    for (int i = tid; i < 3 * C * 9; i += 256) wd_l[i] = a.wd[i];
+    for (int i = tid; i < 3 * C; i += 256) { bd_l[i] = a.bd[i]; bq_l[i] = a.bq[i]; }
+    for (int i = tid; i < C; i += 256) { gam_l[i] = a.ln_w[i]; bet_l[i] = a.ln_b[i]; }
+
+    f32x4 gq[NQT], gnq[NQT], gnk[NQT];
+#pragma unroll
+    for (int r = 0; r < NQT; ++r) { gq[r] = (f32x4){0.f, 0.f, 0.f, 0.f}; gnq[r] = gq[r]; gnk[r] = gq[r]; }
+
+    for (int tile = slab; tile < a.ntiles; tile += a.nslab) {
+        const int tx = tile % a.tiles_x, ty = tile / a.tiles_x;
+        const int x0 = tx * TW, y0 = ty * TH;
+        __syncthreads();                                   // weights visible; previous tile finished with mid
+        const GroupGeom g0 = group_geom(wave, 0, j, y0, x0, h, w), g1 = group_geom(wave, 1, j, y0, x0, h, w);
+        float4 xh0[NS], xh1[NS];
+        load_ln_step<C>(xb, P, kq, g0, gam_l, bet_l, 1e-5f, xh0);
+        load_ln_step<C>(xb, P, kq, g1, gam_l, bet_l, 1e-5f, xh1);
+        const int yo = y0 + wave;
+
+        // ---- Gram rounds: q tile r (plane 0-15) with k tile r (planes 16-31); heads never straddle a tile here
+#pragma unroll
+        for (int r = 0; r < NQT; ++r) {
+            if (r) __syncthreads();
+            phase_a_step<C, NT3>(xh0, w_l + lane, r, NQT + r, bq_l + 16 * r, bq_l + C + 16 * r, mid, PSG, kq, g0);
+            phase_a_step<C, NT3>(xh1, w_l + lane, r, NQT + r, bq_l + 16 * r, bq_l + C + 16 * r, mid, PSG, kq, g1);
+            __syncthreads();
+            // phase B: lane (i = j, kq) owns channel i of the q tile and of the k tile at pixels x0 + 16*st + 4*kq + m
+            const int cq = 16 * r + j, ck = C + 16 * r + j;
+#pragma unroll
+            for (int st = 0; st < 4; ++st) {
+                const int xo = x0 + 16 * st + 4 * kq;
+                const bool ok = yo < h && xo < w;
+                float qa[4], kb[4];
+                stencil4_wide(mid + j * PSG + wave * HC + 16 * st + 4 * kq + 4, wd_l + cq * 9, bd_l[cq], qa);
+                stencil4_wide(mid + (16 + j) * PSG + wave * HC + 16 * st + 4 * kq + 4, wd_l + ck * 9, bd_l[ck], kb);
+#pragma unroll
+                for (int m = 0; m < 4; ++m) {
+                    const float qv = ok ? qa[m] : 0.f, kv = ok ? kb[m] : 0.f;
+                    gq[r] = __builtin_amdgcn_mfma_f32_16x16x4f32(qv, kv, gq[r], 0, 0, 0);
+                    gnq[r] = __builtin_amdgcn_mfma_f32_16x16x4f32(qv, qv, gnq[r], 0, 0, 0);
+                    gnk[r] = __builtin_amdgcn_mfma_f32_16x16x4f32(kv, kv, gnk[r], 0, 0, 0);
+                }
+            }
+        }
+        // ---- v parts: 1x1 -> LDS -> depthwise -> HBM
+#pragma unroll
+        for (int vp = 0; vp < NVP; ++vp) {
+            __syncthreads();
+            const int t0 = 2 * NQT + 2 * vp;
+            phase_a_step<C, NT3>(xh0, w_l + lane, t0, t0 + 1, bq_l + 2 * C + vp * PART, bq_l + 2 * C + vp * PART + 16, mid, PSV, kq, g0);
+            phase_a_step<C, NT3>(xh1, w_l + lane, t0, t0 + 1, bq_l + 2 * C + vp * PART, bq_l + 2 * C + vp * PART + 16, mid, PSV, kq, g1);
+            __syncthreads();
+            const int xo = x0 + 4 * j;
+            if (yo < h && xo < w) {
+#pragma unroll
+                for (int s = 0; s < PART / 4; ++s) {
+                    const int hc = 4 * s + kq, cv = 2 * C + vp * PART + hc;
+                    float v[4];
+                    stencil4_dpp(mid + hc * PSV + wave * HC + 4 * j + 4, j, wd_l + cv * 9, bd_l[cv], v);
+                    *reinterpret_cast<float4*>(vb + (size_t)(vp * PART + hc) * P + (size_t)yo * w + xo) = make_float4(v[0], v[1], v[2], v[3]);
+                }
+            }
+        }
+    }
+    // ---- cross-wave reduction of the Gram tiles in a fixed order, one partial per workgroup
+    __syncthreads();
+    float* red = mid;                                      // [4 waves][16][ROWW] floats = 4224 <= PART * PSG
+#pragma unroll
+    for (int r = 0; r < NQT; ++r) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int row = 4 * kq + q;
+            float* rr = red + (wave * 16 + row) * ROWW;
+            rr[j] = gq[r][q];
+#pragma unroll
+            for (int c = 16; c < 64; c += 16) rr[c + j] = 0.f;
+            if (row == j) { rr[64] = gnq[r][q]; rr[65] = gnk[r][q]; }
+        }
+        __syncthreads();
+        float* dst = a.partial + (((size_t)b * a.nslab + slab) * NQT + r) * 16 * ROWW;
+        for (int i = tid; i < 16 * ROWW; i += 256)
+            dst[i] = ((red[i] + red[16 * ROWW + i]) + red[2 * 16 * ROWW + i]) + red[3 * 16 * ROWW + i];
+        __syncthreads();
+    }
+}
+
+bool fused_attn_supported(int C, int heads, int h, int w) {
+    const int c = heads > 0 ? C / heads : 0;
+    return C == 32 && heads > 0 && C % heads == 0 && c <= 16 && 16 % c == 0 && (w % 4 == 0) &&
+           ((double)C * h * w * 4.0 < 4.0e9);
+}
+
+int fused_attn_plan(int h, int w, int* nslab, size_t* partial_floats, int B, int C) {
+    const int ntiles = cdiv(w, fused::TW) * cdiv(h, fused::TH);
+    int ns = cdiv(ntiles, 8);                   // 8 tiles (2048 px) per workgroup; depends on the image only,
+                                                // never on B: an image's reduction order is batch-invariant
+    if (ns < 1) ns = 1;
+    *nslab = ns;
+    *partial_floats = (size_t)B * ns * (C / 16) * 16 * 66;
+    return RF_OK;
+}
+
+int launch_attn_front(const float* x, float* v, float* partial, int nslab, const float* ln_w, const float* ln_b,
+                      const float* wp, const float* bq, const float* wd, const float* bd, int B, int C, int h, int w, hipStream_t st) {
+    RF_CHECK_ARG((C == 32 || C == 64) && w % 4 == 0 && B <= 65535, "attn_front: unsupported shape C=%d %dx%d", C, h, w);
+    RF_CHECK_ARG(aligned16(x) && aligned16(v), "attn_front: buffers must be 16-byte aligned");
+    AttnFrontArgs a{x, v, partial, ln_w, ln_b, wp, bq, wd, bd, B, h, w, cdiv(w, fused::TW), 0, nslab};
+    a.ntiles = a.tiles_x * cdiv(h, fused::TH);
+    const double px = (double)B * h * w;
+    ProfScope prof(st, C == 32 ? "attn_front_kernel<32>" : "attn_front_kernel<64>", px * (6.0 * C * C + 54.0 * C + 4.0 * C * 16), px * 8.0 * C);
+    const dim3 grid((unsigned)nslab, (unsigned)B);
+    if (C == 32) attn_front_kernel<32><<<grid, 256, 0, st>>>(a);
+    else attn_front_kernel<64><<<grid, 256, 0, st>>>(a);
+    return check_launch("attn_front");
+}
+
+}  // namespace rf

@@ -285,6 +285,21 @@ def whole_model(flca_mod, big):
              in_checksum=checksum(x))
 
 
+@torch.no_grad()
+def config4(flca_mod):
+    """BASELINE configs[3]: RawFormer-L (dim 64) on one SID-Sony-sized frame, packed 4x1424x2128
+    (mosaic 2848x4256), whole frame, untiled: sampled reference outputs + channel statistics."""
+    dim, seed = 64, 10
+    m = fill(flca_mod.RawFormer(dim=dim), 100 + dim)
+    x = t(synth.bayer_mosaic(seed, 1, 2848, 4256))
+    ref = m(x)
+    idx = (synth.uniform01(7, "sample.idx", 4096).astype(np.float64) * ref.numel()).astype(np.int64)
+    save("model_cfg4_L_1x1424x2128", seed=np.int64(seed), dim=np.int64(dim), param_seed=np.int64(100 + dim),
+         shape=np.asarray(ref.shape), idx=idx, samples=ref.reshape(-1)[idx],
+         chan_mean=ref.mean(dim=(0, 2, 3)), chan_min=ref.amin(dim=(0, 2, 3)), chan_max=ref.amax(dim=(0, 2, 3)),
+         in_checksum=checksum(x))
+
+
 def state_dict_keys(flca_mod):
     """Key names and shapes of the reference's state_dict (what test.py:88-91 loads strictly)."""
     import json
@@ -302,10 +317,15 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--big", action="store_true", help="also run BASELINE configs 2-3 (minutes of CPU)")
     ap.add_argument("--only-keys", action="store_true", help="only (re)write state_dict_keys.json")
+    ap.add_argument("--only-cfg4", action="store_true", help="only BASELINE config 4 (RawFormer-L, one 2848x4256 mosaic)")
     args = ap.parse_args()
     if args.only_keys:
         os.makedirs(GOLD, exist_ok=True)
         state_dict_keys(import_reference()[0])
+        return
+    if args.only_cfg4:
+        torch.set_num_threads(8)
+        config4(import_reference()[0])
         return
     os.makedirs(GOLD, exist_ok=True)
     torch.manual_seed(0)

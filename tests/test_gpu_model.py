@@ -175,3 +175,40 @@ def test_checkpoint_round_trip_and_param_update(device, tmp_path):
         m2.conv_out.bias.add_(0.25)
         y1 = m2(x)
     assert float((y1 - y0).abs().max()) > 1e-3
+
+
+def test_baseline_config4_full_frame(device):
+    """BASELINE configs[3]: RawFormer-L (dim 64) on one SID-Sony-sized frame (mosaic 2848x4256,
+    packed 4x1424x2128; level-3 width 266 is not a multiple of 4 -> ragged kernels), untiled,
+    against sampled outputs of the reference's whole-frame CPU forward."""
+    gm = golden("model_cfg4_L_1x1424x2128")
+    m, _ = build(64, int(gm["param_seed"]), device)
+    x = torch.from_numpy(synth.bayer_mosaic(int(gm["seed"]), 1, 2848, 4256)).to(device)
+    assert abs(float(x.double().sum()) - float(gm["in_checksum"])) < 1e-2
+    with torch.no_grad():
+        out = m(x)
+    assert tuple(out.shape) == tuple(gm["shape"])
+    assert maxabs(out.reshape(-1)[torch.from_numpy(gm["idx"]).to(device)], gm["samples"]) <= TOL
+    assert maxabs(out.mean(dim=(0, 2, 3)), gm["chan_mean"]) <= 1e-5
+    assert maxabs(out.amax(dim=(0, 2, 3)), gm["chan_max"]) <= TOL
+
+
+def test_full_frame_tiled_path_on_device(device):
+    """Tile scheduler + stitching with the HIP forward as the per-tile model (single process):
+    every tile must equal the HIP forward of that tile alone, and the frame must be covered."""
+    from bayer_low_light_image_enhancement_amd import tiling
+    dim, seed = 32, 61
+    m, sd = build(dim, seed, device)
+    x = torch.from_numpy(synth.bayer_mosaic(seed, 1, 352, 544)).to(device)      # 22*16 x 34*16: uneven 2x3 grid
+    tiles = tiling.plan_tiles(352, 544, (2, 3), overlap=32)
+    with torch.no_grad():
+        out = tiling.forward_tiled(m, x, tiles)
+        t = tiles[4]
+        alone = m(x[:, :, t.src[0]:t.src[0] + t.src[2], t.src[1]:t.src[1] + t.src[3]].contiguous())
+        # parity of tiled mode = the oracle on the same tile (SURVEY.md section 8e)
+        ref = R.rawformer_forward(sd, x[:, :, t.src[0]:t.src[0] + t.src[2], t.src[1]:t.src[1] + t.src[3]].cpu(),
+                                  R.RawFormerConfig(dim=dim))
+    cy, cx, ch, cw = t.crop
+    assert torch.equal(out[:, :, t.dst[0]:t.dst[0] + ch, t.dst[1]:t.dst[1] + cw], alone[:, :, cy:cy + ch, cx:cx + cw])
+    assert maxabs(alone, ref) <= TOL
+    assert torch.isfinite(out).all()
