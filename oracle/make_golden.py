@@ -294,8 +294,15 @@ def config4(flca_mod):
     x = t(synth.bayer_mosaic(seed, 1, 2848, 4256))
     ref = m(x)
     idx = (synth.uniform01(7, "sample.idx", 4096).astype(np.float64) * ref.numel()).astype(np.int64)
+    # the same reference model in float64: the float32 forward's own noise floor at N = 3 M pixels
+    # (sequential float32 pooling / Gram sums) is what bounds parity at this size
+    ref64 = m.double()(x.double())
+    m.float()
+    log(f"a2  RawFormer cfg4: reference fp32 vs reference fp64 max-abs = {float((ref.double() - ref64).abs().max()):.3e}, "
+        f"mean-abs = {float((ref.double() - ref64).abs().mean()):.3e}")
     save("model_cfg4_L_1x1424x2128", seed=np.int64(seed), dim=np.int64(dim), param_seed=np.int64(100 + dim),
-         shape=np.asarray(ref.shape), idx=idx, samples=ref.reshape(-1)[idx],
+         shape=np.asarray(ref.shape), idx=idx, samples=ref.reshape(-1)[idx], samples_fp64=ref64.reshape(-1)[idx],
+         chan_mean_fp64=ref64.mean(dim=(0, 2, 3)),
          chan_mean=ref.mean(dim=(0, 2, 3)), chan_min=ref.amin(dim=(0, 2, 3)), chan_max=ref.amax(dim=(0, 2, 3)),
          in_checksum=checksum(x))
 
