@@ -9,7 +9,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "csrc", "librawformer_hip.so")
+LIB_PATH = os.environ.get("RF_LIB_PATH") or os.path.join(_HERE, "csrc", "librawformer_hip.so")  # override: diagnostic builds
 
 RF_VARIANT_FLCA = 0
 RF_VARIANT_PLAIN = 1

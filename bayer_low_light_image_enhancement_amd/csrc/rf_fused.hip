@@ -24,6 +24,27 @@
 
 namespace rf {
 
+#ifdef RF_STAMP
+// Diagnostic build only (python -m ...build --stamp): per-phase cycle sums of wave 0 lanes, read back
+// with rf_debug_stamps().  Never compiled into the shipped library.
+__device__ unsigned long long g_stamp[16];
+#define STAMP_DECL unsigned long long st_prev = __builtin_amdgcn_s_memtime(), st_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#define STAMP(i) do { __builtin_amdgcn_sched_barrier(0); unsigned long long t_ = __builtin_amdgcn_s_memtime(); st_acc[i] += t_ - st_prev; st_prev = t_; __builtin_amdgcn_sched_barrier(0); } while (0)
+#define STAMP_FLUSH do { if ((threadIdx.x & 63) == 0) for (int i_ = 0; i_ < 8; ++i_) atomicAdd(&g_stamp[i_], st_acc[i_]); } while (0)
+#else
+#define STAMP_DECL
+#define STAMP(i)
+#define STAMP_FLUSH
+#endif
+
+// Workgroup barrier that orders LDS traffic only.  __syncthreads() makes hipcc drain vmcnt(0) first,
+// which would stall every wave on the next tile's prefetch loads that are deliberately in flight.
+__device__ __forceinline__ void lds_barrier() {
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+}
+
 namespace fused {
 constexpr int TH = 4, TW = 64;          // output tile
 constexpr int HR = TH + 2;              // halo'd rows
@@ -65,15 +86,20 @@ __device__ __forceinline__ GroupGeom group_geom(int wave, int st, int j, int y0,
     return g;
 }
 
-// Load and LayerNorm the wave's input tile for one step: xh[s] = LN(x)[channel 4s + kq][4 px].
+// Input tile of one step: raw loads (issue early: the registers are dead between a tile's last
+// phase A and the next tile's first one, so the next tile is fetched behind the current phase B) ...
 template <int C>
-__device__ __forceinline__ void load_ln_step(const float* __restrict__ xb, int P, int kq, const GroupGeom& g,
-                                             const float* __restrict__ gam_l, const float* __restrict__ bet_l,
-                                             float eps, float4 (&xh)[C / 4]) {
-    constexpr int NS = C / 4;
+__device__ __forceinline__ void load_step(const float* __restrict__ xb, int P, int kq, const GroupGeom& g, float4 (&xh)[C / 4]) {
     const unsigned voff = (unsigned)kq * (unsigned)P + (unsigned)g.goff;
 #pragma unroll
-    for (int s = 0; s < NS; ++s) xh[s] = *reinterpret_cast<const float4*>(xb + (size_t)(4 * s) * P + voff);
+    for (int s = 0; s < C / 4; ++s) xh[s] = *reinterpret_cast<const float4*>(xb + (size_t)(4 * s) * P + voff);
+}
+
+// ... and the exact two-pass LayerNorm over channels, in place: xh[s] = LN(x)[channel 4s + kq][4 px].
+template <int C>
+__device__ __forceinline__ void ln_step(int kq, const float* __restrict__ gam_l, const float* __restrict__ bet_l,
+                                        float eps, float4 (&xh)[C / 4]) {
+    constexpr int NS = C / 4;
     float sum[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int s = 0; s < NS; ++s) { sum[0] += xh[s].x; sum[1] += xh[s].y; sum[2] += xh[s].z; sum[3] += xh[s].w; }
@@ -234,18 +260,31 @@ __global__ void __launch_bounds__(256, 2) ffn_fused_kernel(FfnArgs a) {
     for (int i = tid; i < 2 * C; i += 256) { bd_l[i] = a.bd[i]; b1_l[i] = a.b1[i]; }
     for (int i = tid; i < C; i += 256) { gam_l[i] = a.ln_w[i]; bet_l[i] = a.ln_b[i]; b2_l[i] = a.b2[i]; }
     __syncthreads();
+    STAMP_DECL
 
+    float4 xh0[NS], xh1[NS];
+    GroupGeom g0, g1;
+    if ((int)blockIdx.x < a.ntiles) {
+        const int tx = blockIdx.x % a.tiles_x, ty = blockIdx.x / a.tiles_x;
+        g0 = group_geom(wave, 0, j, ty * TH, tx * TW, h, w);
+        g1 = group_geom(wave, 1, j, ty * TH, tx * TW, h, w);
+        load_step<C>(xb, P, kq, g0, xh0);
+        load_step<C>(xb, P, kq, g1, xh1);
+    }
     for (int tile = blockIdx.x; tile < a.ntiles; tile += gridDim.x) {
         const int tx = tile % a.tiles_x, ty = tile / a.tiles_x;
         const int x0 = tx * TW, y0 = ty * TH;
-        // input tile: two steps of LayerNorm'd activations stay in registers for all parts
-        const GroupGeom g0 = group_geom(wave, 0, j, y0, x0, h, w), g1 = group_geom(wave, 1, j, y0, x0, h, w);
-        float4 xh0[NS], xh1[NS];
-        load_ln_step<C>(xb, P, kq, g0, gam_l, bet_l, 1e-5f, xh0);
-        load_ln_step<C>(xb, P, kq, g1, gam_l, bet_l, 1e-5f, xh1);
+        STAMP(0);
+        // input tile (fetched behind the previous tile's last phase B): LayerNorm in registers
+        ln_step<C>(kq, gam_l, bet_l, 1e-5f, xh0);
+        ln_step<C>(kq, gam_l, bet_l, 1e-5f, xh1);
+        STAMP(1);
 
         const int yo = y0 + wave, xo = x0 + 4 * j;          // this lane's 4 output pixels
         const bool live = yo < h && xo < w;
+        const unsigned voff = (unsigned)(4 * kq) * (unsigned)P + (unsigned)(live ? yo * w + xo : 0);
+        const GroupGeom gw0 = g0, gw1 = g1;                  // this tile's LDS geometry (g0/g1 move on to the next tile)
+        float4 resv[NTO * 4];
         f32x4 acc[NTO][4];
 #pragma unroll
         for (int t = 0; t < NTO; ++t)
@@ -254,11 +293,29 @@ __global__ void __launch_bounds__(256, 2) ffn_fused_kernel(FfnArgs a) {
 
 #pragma unroll
         for (int part = 0; part < NPART; ++part) {
-            __syncthreads();                                 // previous phase B is done with mid
+            lds_barrier();                                 // previous phase B is done with mid
+            STAMP(0);
             // ---- phase A: hidden[32 of part][halo tile] = W1 x^ + b1 -> LDS
-            phase_a_step<C, NT1>(xh0, w1_l + lane, 2 * part, 2 * part + 1, b1_l + part * PART, b1_l + part * PART + 16, mid, PS, kq, g0);
-            phase_a_step<C, NT1>(xh1, w1_l + lane, 2 * part, 2 * part + 1, b1_l + part * PART, b1_l + part * PART + 16, mid, PS, kq, g1);
-            __syncthreads();
+            phase_a_step<C, NT1>(xh0, w1_l + lane, 2 * part, 2 * part + 1, b1_l + part * PART, b1_l + part * PART + 16, mid, PS, kq, gw0);
+            phase_a_step<C, NT1>(xh1, w1_l + lane, 2 * part, 2 * part + 1, b1_l + part * PART, b1_l + part * PART + 16, mid, PS, kq, gw1);
+            STAMP(2);
+            if (part == NPART - 1) {
+                // the input registers are dead now: fetch the next tile, and this tile's residual rows,
+                // behind the last phase B (all loads are issued before this tile's stores)
+                const int tn = tile + gridDim.x;
+                if (tn < a.ntiles) {
+                    g0 = group_geom(wave, 0, j, (tn / a.tiles_x) * TH, (tn % a.tiles_x) * TW, h, w);
+                    g1 = group_geom(wave, 1, j, (tn / a.tiles_x) * TH, (tn % a.tiles_x) * TW, h, w);
+                    load_step<C>(xb, P, kq, g0, xh0);
+                    load_step<C>(xb, P, kq, g1, xh1);
+                }
+#pragma unroll
+                for (int t = 0; t < NTO; ++t)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) resv[t * 4 + r] = *reinterpret_cast<const float4*>(xb + (size_t)(16 * t + r) * P + voff);
+            }
+            lds_barrier();
+            STAMP(0);
             // ---- phase B: depthwise 3x3 + GELU in registers, straight into the second GEMM
 #pragma unroll
             for (int s = 0; s < PART / 4; ++s) {
@@ -274,22 +331,24 @@ __global__ void __launch_bounds__(256, 2) ffn_fused_kernel(FfnArgs a) {
                     for (int q = 0; q < 4; ++q) acc[t][q] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, v[q], acc[t][q], 0, 0, 0);
                 }
             }
+            STAMP(3);
         }
         // ---- epilogue: + b2 + residual
         if (live) {
-            const unsigned voff = (unsigned)(4 * kq) * (unsigned)P + (unsigned)(yo * w + xo);
 #pragma unroll
             for (int t = 0; t < NTO; ++t)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const int cu = 16 * t + r;
                     const float bs = b2_l[cu + 4 * kq];
-                    const float4 rv = *reinterpret_cast<const float4*>(xb + (size_t)cu * P + voff);
+                    const float4 rv = resv[t * 4 + r];
                     *reinterpret_cast<float4*>(ob + (size_t)cu * P + voff) =
                         make_float4(acc[t][0][r] + bs + rv.x, acc[t][1][r] + bs + rv.y, acc[t][2][r] + bs + rv.z, acc[t][3][r] + bs + rv.w);
                 }
         }
+        STAMP(4);
     }
+    STAMP_FLUSH;
 }
 
 bool fused_ffn_supported(int C, int hidden, int h, int w) {
@@ -356,24 +415,37 @@ __global__ void __launch_bounds__(256, 2) attn_front_kernel(AttnFrontArgs a) {
     f32x4 gq[NQT], gnq[NQT], gnk[NQT];
 #pragma unroll
     for (int r = 0; r < NQT; ++r) { gq[r] = (f32x4){0.f, 0.f, 0.f, 0.f}; gnq[r] = gq[r]; gnk[r] = gq[r]; }
+    STAMP_DECL
 
+    float4 xh0[NS], xh1[NS];
+    GroupGeom gn0, gn1;
+    if (slab < a.ntiles) {
+        gn0 = group_geom(wave, 0, j, (slab / a.tiles_x) * TH, (slab % a.tiles_x) * TW, h, w);
+        gn1 = group_geom(wave, 1, j, (slab / a.tiles_x) * TH, (slab % a.tiles_x) * TW, h, w);
+        load_step<C>(xb, P, kq, gn0, xh0);
+        load_step<C>(xb, P, kq, gn1, xh1);
+    }
     for (int tile = slab; tile < a.ntiles; tile += a.nslab) {
         const int tx = tile % a.tiles_x, ty = tile / a.tiles_x;
         const int x0 = tx * TW, y0 = ty * TH;
-        __syncthreads();                                   // weights visible; previous tile finished with mid
-        const GroupGeom g0 = group_geom(wave, 0, j, y0, x0, h, w), g1 = group_geom(wave, 1, j, y0, x0, h, w);
-        float4 xh0[NS], xh1[NS];
-        load_ln_step<C>(xb, P, kq, g0, gam_l, bet_l, 1e-5f, xh0);
-        load_ln_step<C>(xb, P, kq, g1, gam_l, bet_l, 1e-5f, xh1);
+        lds_barrier();                                   // weights visible; previous tile finished with mid
+        STAMP(0);
+        const GroupGeom g0 = gn0, g1 = gn1;                // geometry of this tile (its loads were issued a tile ago)
+        ln_step<C>(kq, gam_l, bet_l, 1e-5f, xh0);
+        ln_step<C>(kq, gam_l, bet_l, 1e-5f, xh1);
         const int yo = y0 + wave;
+        STAMP(1);
 
         // ---- Gram rounds: q tile r (plane 0-15) with k tile r (planes 16-31); heads never straddle a tile here
 #pragma unroll
         for (int r = 0; r < NQT; ++r) {
-            if (r) __syncthreads();
+            if (r) lds_barrier();
+            STAMP(0);
             phase_a_step<C, NT3>(xh0, w_l + lane, r, NQT + r, bq_l + 16 * r, bq_l + C + 16 * r, mid, PSG, kq, g0);
             phase_a_step<C, NT3>(xh1, w_l + lane, r, NQT + r, bq_l + 16 * r, bq_l + C + 16 * r, mid, PSG, kq, g1);
-            __syncthreads();
+            STAMP(2);
+            lds_barrier();
+            STAMP(0);
             // phase B: lane (i = j, kq) owns channel i of the q tile and of the k tile at pixels x0 + 16*st + 4*kq + m
             const int cq = 16 * r + j, ck = C + 16 * r + j;
 #pragma unroll
@@ -391,15 +463,28 @@ __global__ void __launch_bounds__(256, 2) attn_front_kernel(AttnFrontArgs a) {
                     gnk[r] = __builtin_amdgcn_mfma_f32_16x16x4f32(kv, kv, gnk[r], 0, 0, 0);
                 }
             }
+            STAMP(3);
         }
         // ---- v parts: 1x1 -> LDS -> depthwise -> HBM
 #pragma unroll
         for (int vp = 0; vp < NVP; ++vp) {
-            __syncthreads();
+            lds_barrier();
+            STAMP(0);
             const int t0 = 2 * NQT + 2 * vp;
             phase_a_step<C, NT3>(xh0, w_l + lane, t0, t0 + 1, bq_l + 2 * C + vp * PART, bq_l + 2 * C + vp * PART + 16, mid, PSV, kq, g0);
             phase_a_step<C, NT3>(xh1, w_l + lane, t0, t0 + 1, bq_l + 2 * C + vp * PART, bq_l + 2 * C + vp * PART + 16, mid, PSV, kq, g1);
-            __syncthreads();
+            STAMP(2);
+            if (vp == NVP - 1) {   // input registers are dead: fetch the next tile behind this phase B (before its stores)
+                const int tn = tile + a.nslab;
+                if (tn < a.ntiles) {
+                    gn0 = group_geom(wave, 0, j, (tn / a.tiles_x) * TH, (tn % a.tiles_x) * TW, h, w);
+                    gn1 = group_geom(wave, 1, j, (tn / a.tiles_x) * TH, (tn % a.tiles_x) * TW, h, w);
+                    load_step<C>(xb, P, kq, gn0, xh0);
+                    load_step<C>(xb, P, kq, gn1, xh1);
+                }
+            }
+            lds_barrier();
+            STAMP(0);
             const int xo = x0 + 4 * j;
             if (yo < h && xo < w) {
 #pragma unroll
@@ -410,8 +495,10 @@ __global__ void __launch_bounds__(256, 2) attn_front_kernel(AttnFrontArgs a) {
                     *reinterpret_cast<float4*>(vb + (size_t)(vp * PART + hc) * P + (size_t)yo * w + xo) = make_float4(v[0], v[1], v[2], v[3]);
                 }
             }
+            STAMP(4);
         }
     }
+    STAMP_FLUSH;
     // ---- cross-wave reduction of the Gram tiles in a fixed order, one partial per workgroup
     __syncthreads();
     float* red = mid;                                      // [4 waves][16][ROWW] floats = 4224 <= PART * PSG
@@ -463,5 +550,13 @@ int launch_attn_front(const float* x, float* v, float* partial, int nslab, const
     else attn_front_kernel<64><<<grid, 256, 0, st>>>(a);
     return check_launch("attn_front");
 }
+
+#ifdef RF_STAMP
+extern "C" int rf_debug_stamps(unsigned long long* out8) {   // diagnostic build only: read and reset the phase cycle sums
+    unsigned long long z[16] = {0};
+    if (hipMemcpyFromSymbol(out8, HIP_SYMBOL(g_stamp), 8 * sizeof(unsigned long long)) != hipSuccess) return -1;
+    return hipMemcpyToSymbol(HIP_SYMBOL(g_stamp), z, sizeof(z)) == hipSuccess ? 0 : -1;
+}
+#endif
 
 }  // namespace rf
