@@ -34,7 +34,10 @@ int gram_plan(int B, int C, int heads, int P, int* nslab, int* slab, size_t* par
     const int NTq = cdiv(C, 16);
     // the slab split depends only on (C, P), never on B: an image's result is bitwise the same
     // alone and inside a batch
-    int ns = cdiv(P, 4096);
+    int target = P / 64;                       // pixels per slab: at most 64 slabs per image,
+    if (target < 1024) target = 1024;          // at least 1024 px so small levels still fill the GPU
+    if (target > 8192) target = 8192;
+    int ns = cdiv(P, target);
     const int maxs = cdiv(P, 256);
     if (ns > maxs) ns = maxs;
     if (ns < 1) ns = 1;
@@ -145,31 +148,46 @@ __global__ void __launch_bounds__(256) attn_fold_kernel(const float* __restrict_
     __shared__ float S[64][65];
     __shared__ float nq[64], nk[64];
     const float* pb = partial + (size_t)b * nslab * NT * 16 * kRowW;
-    // 1. reduce the slab partials (fixed order)
-    for (int idx = threadIdx.x; idx < c * c + 2 * c; idx += 256) {
-        int qch, col;
-        if (idx < c * c) {
-            const int ii = idx / c, jj = idx % c;
-            qch = hd * c + ii;
-            const int kch = hd * c + jj;
-            int tklo, nb;
-            band_of(qch >> 4, C, c, &tklo, &nb);
-            col = ((kch >> 4) - tklo) * 16 + (kch & 15);
-        } else if (idx < c * c + c) {
-            qch = hd * c + (idx - c * c);
-            col = kMaxBand * 16;
-        } else {
-            qch = hd * c + (idx - c * c - c);
-            col = kMaxBand * 16 + 1;
-        }
-        const float* src = pb + ((size_t)(qch >> 4) * 16 + (qch & 15)) * kRowW + col;
+    // 1. reduce the slab partials: value v is summed by RS threads over interleaved slabs, then the RS
+    //    sub-sums are combined in a fixed order (deterministic, and parallel when c*c + 2c < 256)
+    __shared__ float sub[256];
+    const int nval = c * c + 2 * c;
+    int RS = 256 / nval;
+    if (RS < 1) RS = 1;
+    if (RS > 16) RS = 16;
+    for (int base = 0; base < nval; base += 256 / RS) {
+        const int vi = base + threadIdx.x / RS, rs = threadIdx.x % RS;
         float s = 0.f;
-        for (int sl = 0; sl < nslab; ++sl) s += src[(size_t)sl * NT * 16 * kRowW];
-        if (idx < c * c) S[idx / c][idx % c] = s;
-        else if (idx < c * c + c) nq[idx - c * c] = s;
-        else nk[idx - c * c - c] = s;
+        if (vi < nval && threadIdx.x / RS < 256 / RS) {
+            int qch, col;
+            if (vi < c * c) {
+                const int ii = vi / c, jj = vi % c;
+                qch = hd * c + ii;
+                const int kch = hd * c + jj;
+                int tklo, nb;
+                band_of(qch >> 4, C, c, &tklo, &nb);
+                col = ((kch >> 4) - tklo) * 16 + (kch & 15);
+            } else if (vi < c * c + c) {
+                qch = hd * c + (vi - c * c);
+                col = kMaxBand * 16;
+            } else {
+                qch = hd * c + (vi - c * c - c);
+                col = kMaxBand * 16 + 1;
+            }
+            const float* src = pb + ((size_t)(qch >> 4) * 16 + (qch & 15)) * kRowW + col;
+            for (int sl = rs; sl < nslab; sl += RS) s += src[(size_t)sl * NT * 16 * kRowW];
+        }
+        sub[threadIdx.x] = s;
+        __syncthreads();
+        if (rs == 0 && vi < nval && threadIdx.x / RS < 256 / RS) {
+            float t = 0.f;
+            for (int q = 0; q < RS; ++q) t += sub[threadIdx.x + q];
+            if (vi < c * c) S[vi / c][vi % c] = t;
+            else if (vi < c * c + c) nq[vi - c * c] = t;
+            else nk[vi - c * c - c] = t;
+        }
+        __syncthreads();
     }
-    __syncthreads();
     // 2. cosine similarity * temperature, softmax over j (F.normalize clamps the norm at 1e-12)
     if (threadIdx.x < c) {
         const int ii = threadIdx.x;

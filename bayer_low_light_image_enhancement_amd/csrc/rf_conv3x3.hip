@@ -23,15 +23,16 @@
 namespace rf {
 
 static constexpr int KC = 8;        // input channels per LDS chunk
-static constexpr int PS = 448;      // LDS plane stride in floats (multiple of 64)
 
-template <int NCO, int LOG2_RW>
+template <int NCO, int LOG2_RW, int RPW>
 __global__ void __launch_bounds__(256, 2) conv3x3_kernel(Conv3x3Args a, int ngroups, int tiles_x, int vec) {
-    constexpr int RW = 1 << LOG2_RW;         // rows per wave
+    constexpr int RW = 1 << LOG2_RW;         // rows one MFMA pixel group spans (narrow images)
     constexpr int TW = 64 / RW;              // tile width
-    constexpr int TH = 4 * RW;               // tile height
+    constexpr int TH = 4 * RW * RPW;         // tile height: every wave owns RPW row groups (RPW = 2 for few output
+                                             // channels: twice the MFMAs per staged weight, 25 % less halo)
     constexpr int RS = TW + 8;               // LDS row stride
-    static_assert((TH + 2) * RS <= PS, "plane does not fit");
+    static_assert(RPW == 1 || RW == 1, "two row groups per wave only with one row per group");
+    constexpr int PS = ((TH + 2) * RS + 63) / 64 * 64;   // LDS plane stride in floats (multiple of 64)
     constexpr int NIN = KC * (TH + 2) * (TW + 2);       // staged input elements per chunk
     constexpr int EPT = (NIN + 255) / 256;              // ... per thread
     constexpr int NW4 = 2 * 9 * NCO * 16;               // staged weight float4 per chunk
@@ -111,11 +112,13 @@ __global__ void __launch_bounds__(256, 2) conv3x3_kernel(Conv3x3Args a, int ngro
         }
     };
 
-    f32x4 acc[NCO][4];
+    f32x4 acc[RPW][NCO][4];
 #pragma unroll
-    for (int t = 0; t < NCO; ++t)
+    for (int rr = 0; rr < RPW; ++rr)
 #pragma unroll
-        for (int g = 0; g < 4; ++g) acc[t][g] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        for (int t = 0; t < NCO; ++t)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) acc[rr][t][g] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
     load_chunk(0);
     store_chunk(0);
@@ -126,21 +129,26 @@ __global__ void __launch_bounds__(256, 2) conv3x3_kernel(Conv3x3Args a, int ngro
         const float* lds_w = lds_in + KC * PS;
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
-            const float* lp = lds_in + (ks * 4 + kq) * PS + (wave * RW + rowj) * RS + 4 * cg;
+            const float* lp = lds_in + (ks * 4 + kq) * PS + (wave * RW * RPW + rowj) * RS + 4 * cg;
 #pragma unroll
-            for (int dy = 0; dy < 3; ++dy) {
-                const float4 lo = *reinterpret_cast<const float4*>(lp + dy * RS);
-                const float4 hi = *reinterpret_cast<const float4*>(lp + dy * RS + 4);
+            for (int ir = 0; ir < RPW + 2; ++ir) {          // input row group ir feeds output row groups ir-2 .. ir
+                const float4 lo = *reinterpret_cast<const float4*>(lp + ir * RS);
+                const float4 hi = *reinterpret_cast<const float4*>(lp + ir * RS + 4);
                 const float v[6] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y};
 #pragma unroll
-                for (int dx = 0; dx < 3; ++dx) {
-                    const float* wl = lds_w + ((ks * 9 + dy * 3 + dx) * NCO) * 64 + lane;
+                for (int rr = 0; rr < RPW; ++rr) {
+                    const int dy = ir - rr;
+                    if (dy < 0 || dy > 2) continue;
 #pragma unroll
-                    for (int t = 0; t < NCO; ++t) {
-                        const float av = wl[t * 64];
+                    for (int dx = 0; dx < 3; ++dx) {
+                        const float* wl = lds_w + ((ks * 9 + dy * 3 + dx) * NCO) * 64 + lane;
 #pragma unroll
-                        for (int g = 0; g < 4; ++g)
-                            acc[t][g] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, v[g + dx], acc[t][g], 0, 0, 0);
+                        for (int t = 0; t < NCO; ++t) {
+                            const float av = wl[t * 64];
+#pragma unroll
+                            for (int g = 0; g < 4; ++g)
+                                acc[rr][t][g] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, v[g + dx], acc[rr][t][g], 0, 0, 0);
+                        }
                     }
                 }
             }
@@ -150,10 +158,12 @@ __global__ void __launch_bounds__(256, 2) conv3x3_kernel(Conv3x3Args a, int ngro
     }
 
     // ---- epilogue
-    const int y = y0 + wave * RW + rowj;
-    const int x = x0 + 4 * cg;
-    if (y >= h || x >= w) return;
     float* outb = a.out + (size_t)b * a.out_bstride;
+    const int x = x0 + 4 * cg;
+#pragma unroll
+    for (int rr = 0; rr < RPW; ++rr) {
+    const int y = y0 + (wave * RPW + rr) * RW + rowj;
+    if (y >= h || x >= w) continue;
 #pragma unroll
     for (int t = 0; t < NCO; ++t) {
         if (t0 + t >= NT) break;
@@ -164,7 +174,7 @@ __global__ void __launch_bounds__(256, 2) conv3x3_kernel(Conv3x3Args a, int ngro
             const float bs = (a.bias && co < a.Cout) ? a.bias[co] : 0.f;
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
-                float u = acc[t][g][r] + bs;
+                float u = acc[rr][t][g][r] + bs;
                 if (a.act == 1) u = u > 0.f ? u : 0.2f * u;
                 if (a.clamp_out) u = fminf(fmaxf(u, 0.f), 1.f);
                 v[r][g] = u;
@@ -227,20 +237,22 @@ __global__ void __launch_bounds__(256, 2) conv3x3_kernel(Conv3x3Args a, int ngro
             }
         }
     }
+    }
 }
 
 template <int NCO>
 static void launch_rw(const Conv3x3Args& a, int ngroups, int vec, hipStream_t st) {
     // pick the tile shape from the image width: 64x4, 32x8 or 16x16 pixels
     if (a.w > 32) {
+        // (two row groups per wave, RPW = 2, was measured for NCO <= 2: no gain -- 231 VGPRs -- so RPW = 1 everywhere)
         const int txs = cdiv(a.w, 64), tys = cdiv(a.h, 4);
-        conv3x3_kernel<NCO, 0><<<dim3((unsigned)(ngroups * txs * tys), (unsigned)a.B), 256, 0, st>>>(a, ngroups, txs, vec);
+        conv3x3_kernel<NCO, 0, 1><<<dim3((unsigned)(ngroups * txs * tys), (unsigned)a.B), 256, 0, st>>>(a, ngroups, txs, vec);
     } else if (a.w > 16) {
         const int txs = cdiv(a.w, 32), tys = cdiv(a.h, 8);
-        conv3x3_kernel<NCO, 1><<<dim3((unsigned)(ngroups * txs * tys), (unsigned)a.B), 256, 0, st>>>(a, ngroups, txs, vec);
+        conv3x3_kernel<NCO, 1, 1><<<dim3((unsigned)(ngroups * txs * tys), (unsigned)a.B), 256, 0, st>>>(a, ngroups, txs, vec);
     } else {
         const int txs = cdiv(a.w, 16), tys = cdiv(a.h, 16);
-        conv3x3_kernel<NCO, 2><<<dim3((unsigned)(ngroups * txs * tys), (unsigned)a.B), 256, 0, st>>>(a, ngroups, txs, vec);
+        conv3x3_kernel<NCO, 2, 1><<<dim3((unsigned)(ngroups * txs * tys), (unsigned)a.B), 256, 0, st>>>(a, ngroups, txs, vec);
     }
 }
 
@@ -256,7 +268,7 @@ int launch_conv3x3(const Conv3x3Args& a, hipStream_t st) {
     const int ngroups = cdiv(NT, nco);
     const int vec = (a.w % 4 == 0) && aligned16(a.out) && (a.out_bstride % 4 == 0);
     char key[64];
-    snprintf(key, sizeof(key), "conv3x3_kernel<%d, %d>", nco, a.w > 32 ? 0 : (a.w > 16 ? 1 : 2));
+    snprintf(key, sizeof(key), "conv3x3_kernel<%d, %d, 1>", nco, a.w > 32 ? 0 : (a.w > 16 ? 1 : 2));
     const double px = (double)a.B * a.h * a.w;
     ProfScope prof(st, key, 18.0 * a.Cin * a.Cout * px, 4.0 * px * (a.Cin + a.Cout));
     switch (nco) {

@@ -163,6 +163,7 @@ int launch_guidance_level(const float* scratch, float* guide, int B, int H, int 
 // sigmoid / tanh use v_exp_f32 + v_rcp_f32 (about 1 ulp each, far below the parity budget).
 // The 36 weights of a channel are wave-uniform (scalar loads).  Per-block channel sums feed the
 // squeeze-excite pooling without atomics.
+static constexpr int kFlcaCG = 32;   // channels per workgroup: (pixel block, channel group, image) grid keeps small levels parallel
 int flca_nblk(int h, int w) { return (w % 4 == 0) ? cdiv(h * w, 1024) : cdiv(h * w, 256); }
 
 __device__ __forceinline__ float fast_sigmoid(float x) { return __builtin_amdgcn_rcpf(1.0f + __expf(-x)); }
@@ -172,8 +173,9 @@ __global__ void __launch_bounds__(256) flca_spatial_vec_kernel(FlcaSpatialArgs a
                                                                const float* __restrict__ w_high, const float* __restrict__ w_chr,
                                                                const float* __restrict__ feat, float* __restrict__ xs) {
     const int blk = blockIdx.x;
-    const size_t b = blockIdx.y;
+    const size_t b = blockIdx.z;
     const int h = a.h, w = a.w, P = h * w, C = a.C;
+    const int c_lo = blockIdx.y * kFlcaCG, c_hi = (c_lo + kFlcaCG < C) ? c_lo + kFlcaCG : C;   // this workgroup's channels
     const int p = (blk * 256 + threadIdx.x) * 4;
     const bool live = p < P;
     const int y = live ? p / w : 0, x = live ? p - (p / w) * w : 0;
@@ -194,13 +196,13 @@ __global__ void __launch_bounds__(256) flca_spatial_vec_kernel(FlcaSpatialArgs a
             nb[pl][dy][5] = (rok && x + 4 < w) ? r : 0.f;
         }
     const float al = *a.alpha, be = *a.beta, ga = *a.gamma;
-    __shared__ float red[512][4];
+    __shared__ float red[kFlcaCG][4];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const float* fb = feat + b * (size_t)C * P + (live ? p : 0);
     float* xb = xs + b * (size_t)C * P + p;
-    float4 fcur = *reinterpret_cast<const float4*>(fb);
-    for (int c = 0; c < C; ++c) {
-        const float4 fnext = *reinterpret_cast<const float4*>(fb + (size_t)(c + 1 < C ? c + 1 : c) * P);
+    float4 fcur = *reinterpret_cast<const float4*>(fb + (size_t)c_lo * P);
+    for (int c = c_lo; c < c_hi; ++c) {
+        const float4 fnext = *reinterpret_cast<const float4*>(fb + (size_t)(c + 1 < c_hi ? c + 1 : c) * P);
         const float* wl = w_low + c * 9;
         const float* wh = w_high + c * 9;
         const float* wc = w_chr + c * 18;
@@ -229,12 +231,12 @@ __global__ void __launch_bounds__(256) flca_spatial_vec_kernel(FlcaSpatialArgs a
         }
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
-        if (lane == 0) red[c][wave] = s;
+        if (lane == 0) red[c - c_lo][wave] = s;
         fcur = fnext;
     }
     __syncthreads();
-    for (int c = threadIdx.x; c < C; c += 256)
-        a.partial[(b * a.nblk + blk) * C + c] = (red[c][0] + red[c][1]) + (red[c][2] + red[c][3]);
+    for (int c = c_lo + threadIdx.x; c < c_hi; c += 256)
+        a.partial[(b * a.nblk + blk) * C + c] = (red[c - c_lo][0] + red[c - c_lo][1]) + (red[c - c_lo][2] + red[c - c_lo][3]);
 }
 
 __global__ void __launch_bounds__(256) flca_spatial_kernel(FlcaSpatialArgs a) {
@@ -294,7 +296,7 @@ int launch_flca_spatial(const FlcaSpatialArgs& a, hipStream_t st) {
     RF_CHECK_ARG(vec || a.w % 4 != 0, "flca: feature / guidance buffers must be 16-byte aligned");
     ProfScope prof(st, vec ? "flca_spatial_vec_kernel" : "flca_spatial_kernel", 80.0 * el, 8.0 * el);
     if (vec)
-        flca_spatial_vec_kernel<<<dim3((unsigned)a.nblk, (unsigned)a.B), 256, 0, st>>>(a, a.w_low, a.w_high, a.w_chr, a.feat, a.xs);
+        flca_spatial_vec_kernel<<<dim3((unsigned)a.nblk, (unsigned)cdiv(a.C, kFlcaCG), (unsigned)a.B), 256, 0, st>>>(a, a.w_low, a.w_high, a.w_chr, a.feat, a.xs);
     else
         flca_spatial_kernel<<<dim3((unsigned)a.nblk, (unsigned)a.B), 256, 0, st>>>(a);
     return check_launch("flca_spatial");
