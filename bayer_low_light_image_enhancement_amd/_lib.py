@@ -56,6 +56,10 @@ SIGNATURES = {
     "rf_convT2x2": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
     "rf_chan_attn_scratch_bytes": (_i, [_i, _i, _i, _i, _i, _psz]),
     "rf_chan_attn": (_i, [_vp] * 10 + [_i] * 5 + [_vp]),
+    "rf_transformer_block_scratch_bytes": (_i, [_i, _i, _i, _i, _i, _i, _psz]),
+    "rf_transformer_block": (_i, [_vp, _vp, C.POINTER(_vp), _vp, _i, _i, _i, _i, _i, _i, _vp]),
+    "rf_flca_scratch_bytes": (_i, [_i, _i, _i, _i, _psz]),
+    "rf_flca": (_i, [_vp, _vp, _vp, C.POINTER(_vp), _vp, _i, _i, _i, _i, _vp]),
     "rf_guidance_scratch_bytes": (_i, [_i, _i, _i, _psz]),
     "rf_flca_guidance": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
 }

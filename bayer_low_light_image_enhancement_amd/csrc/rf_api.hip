@@ -283,6 +283,70 @@ int rf_chan_attn(const float* in, float* out, const float* qkv_w, const float* q
     return launch_conv1x1(av, st);
 }
 
+// scratch layout of rf_transformer_block: packed qkv | packed pw1 | packed pw2 | run_transformer buffers
+struct TbScratch { size_t wqkv, w1, w2, bufs, total; TbBufOffsets o; };
+static void tb_scratch(int B, int C, int heads, int hc, int h, int w, TbScratch* s) {
+    size_t off = 0;
+    auto take = [&](size_t f) { const size_t r = off; off += align_up(f, 64); return r; };
+    s->wqkv = take(packed1x1_floats(C, 3 * C));
+    s->w1 = take(packed1x1_floats(C, hc));
+    s->w2 = take(packed1x1_floats(hc, C));
+    s->bufs = off;
+    s->total = off + transformer_scratch_floats(B, C, heads, hc, h, w, &s->o);
+}
+
+int rf_transformer_block_scratch_bytes(int B, int C, int heads, int ffn_expansion, int h, int w, size_t* bytes) {
+    RF_CHECK_ARG(bytes && B > 0 && C > 0 && heads > 0 && C % heads == 0 && ffn_expansion > 0 && h > 0 && w > 0, "transformer_block_scratch_bytes: bad arguments");
+    TbScratch s;
+    tb_scratch(B, C, heads, C * ffn_expansion, h, w, &s);
+    *bytes = s.total * sizeof(float);
+    return RF_OK;
+}
+
+int rf_transformer_block(const float* in, float* out, const float* const* prm, void* scratch,
+                         int B, int C, int heads, int ffn_expansion, int h, int w, void* stream) {
+    RF_CHECK_ARG(in && out && prm && scratch && aligned16(scratch), "transformer_block: bad arguments");
+    RF_CHECK_ARG(B > 0 && C % 4 == 0 && heads > 0 && C % heads == 0 && C / heads <= 64, "transformer_block: unsupported C=%d heads=%d", C, heads);
+    for (int i = 0; i < 17; ++i) RF_CHECK_ARG(prm[i] != nullptr, "transformer_block: parameter %d is null", i);
+    hipStream_t st = (hipStream_t)stream;
+    const int hc = C * ffn_expansion;
+    TbScratch s;
+    tb_scratch(B, C, heads, hc, h, w, &s);
+    float* ws = (float*)scratch;
+    // prm: norm1.w, norm1.b, temperature, qkv.w, qkv.b, qkv_dwconv.w, qkv_dwconv.b, project_out.w, project_out.b,
+    //      norm2.w, norm2.b, pointwise1.w, pointwise1.b, depthwise.w, depthwise.b, pointwise2.w, pointwise2.b
+    RF_TRY(pack_1x1(prm[3], ws + s.wqkv, 3 * C, C, C, 1, st));
+    RF_TRY(pack_1x1(prm[11], ws + s.w1, hc, C, C, 1, st));
+    RF_TRY(pack_1x1(prm[15], ws + s.w2, C, hc, hc, 1, st));
+    TbParams p{prm[0], prm[1], prm[2], ws + s.wqkv, prm[4], prm[5], prm[6], prm[7], prm[8],
+               prm[9], prm[10], ws + s.w1, prm[12], prm[13], prm[14], ws + s.w2, prm[16]};
+    return run_transformer(p, in, out, ws + s.bufs, s.o, B, C, heads, hc, h, w, st);
+}
+
+int rf_flca_scratch_bytes(int B, int C, int h, int w, size_t* bytes) {
+    RF_CHECK_ARG(bytes && B > 0 && C > 0 && h > 0 && w > 0, "flca_scratch_bytes: bad arguments");
+    *bytes = (align_up((size_t)B * flca_nblk(h, w) * C, 64) + align_up((size_t)B * C, 64)) * sizeof(float);
+    return RF_OK;
+}
+
+int rf_flca(const float* feat, const float* guide, float* out, const float* const* prm, void* scratch,
+            int B, int C, int h, int w, void* stream) {
+    RF_CHECK_ARG(feat && guide && out && prm && scratch && aligned16(scratch), "flca: bad arguments");
+    for (int i = 0; i < 10; ++i) RF_CHECK_ARG(prm[i] != nullptr, "flca: parameter %d is null", i);
+    hipStream_t st = (hipStream_t)stream;
+    float* partial = (float*)scratch;
+    float* ch = partial + align_up((size_t)B * flca_nblk(h, w) * C, 64);
+    // prm: alpha, beta, gamma, low_attn.0.w, high_attn.0.w, chroma_attn.0.w, se.1.w, se.1.b, se.3.w, se.3.b
+    FlcaSpatialArgs a{};
+    a.feat = feat; a.xs = out; a.guide = guide;
+    a.alpha = prm[0]; a.beta = prm[1]; a.gamma = prm[2]; a.w_low = prm[3]; a.w_high = prm[4]; a.w_chr = prm[5];
+    a.partial = partial; a.B = B; a.C = C; a.h = h; a.w = w; a.nblk = flca_nblk(h, w);
+    RF_TRY(launch_flca_spatial(a, st));
+    const int hid = C / 8 > 8 ? C / 8 : 8;
+    RF_TRY(launch_flca_se(partial, a.nblk, h * w, prm[6], prm[7], prm[8], prm[9], hid, ch, B, C, st));
+    return launch_scale_channels(out, ch, B, C, h * w, st);
+}
+
 int rf_guidance_scratch_bytes(int B, int H, int W, size_t* bytes) {
     RF_CHECK_ARG(bytes && B > 0 && H > 0 && W > 0, "guidance_scratch_bytes: bad arguments");
     *bytes = guidance_scratch_floats(B, H, W) * sizeof(float);

@@ -1,0 +1,110 @@
+// TransformerBlock schedule (a7):  x1 = x + attn(LN1(x));  out = x1 + ffn(LN2(x1)).
+// Shared by the whole-model forward (rf_model.hip) and the operator entry point
+// rf_transformer_block (rf_api.hip).  Host code only.
+#include <cstdlib>
+#include "rf_common.h"
+
+namespace rf {
+
+#define RF_TRY(expr)            \
+    do {                        \
+        const int rc_ = (expr); \
+        if (rc_) return rc_;    \
+    } while (0)
+
+size_t transformer_scratch_floats(int B, int C, int heads, int hc, int h, int w, TbBufOffsets* o) {
+    const size_t P = (size_t)h * w;
+    size_t off = 0;
+    auto take = [&](size_t f) { const size_t r = off; off += align_up(f, 64); return r; };
+    const size_t wide = (size_t)(3 * C > hc ? 3 * C : hc);
+    o->bufA = take((size_t)B * wide * P);
+    o->bufB = take((size_t)B * wide * P);
+    o->x1 = take((size_t)B * C * P);
+    int ns, sl;
+    size_t pf = 0, pf2 = 0;
+    gram_plan(B, C, heads, (int)P, &ns, &sl, &pf);
+    if (fused_attn_supported(C, heads, h, w)) fused_attn_plan(h, w, &ns, &pf2, B, C);
+    o->partial = take(pf > pf2 ? pf : pf2);
+    o->wfold = take((size_t)B * packed1x1_floats(C, C));
+    return off;
+}
+
+int run_transformer(const TbParams& p, const float* in, float* out, float* ws, const TbBufOffsets& o,
+                    int B, int C, int heads, int hc, int hh, int ww, hipStream_t st) {
+    const int Pn = hh * ww;
+    float* bufA = ws + o.bufA;
+    float* bufB = ws + o.bufB;
+    float* x1 = ws + o.x1;
+    float* partial = ws + o.partial;
+    float* wfold = ws + o.wfold;
+    const bool no_fuse = getenv("RF_NO_FUSE") != nullptr;   // diagnostic: force the op-by-op path
+
+    // x + attn(LN1(x)) ---------------------------------------------------------------------
+    Conv1x1Args av{};
+    int nslab = 0;
+    if (!no_fuse && fused_attn_supported(C, heads, hh, ww)) {
+        // LN1 -> qkv 1x1 -> depthwise 3x3 -> {Gram partials, v} in one kernel: qkv never reaches HBM
+        size_t pf;
+        RF_TRY(fused_attn_plan(hh, ww, &nslab, &pf, B, C));
+        RF_TRY(launch_attn_front(in, bufB, partial, nslab, p.ln1_w, p.ln1_b, p.qkv_wp, p.qkv_b, p.qkv_dw_w, p.qkv_dw_b, B, C, hh, ww, st));
+        av.x1 = bufB; av.x1_bstride = (int64_t)C * Pn;
+    } else {
+        Conv1x1Args q{};
+        q.x1 = in; q.C1 = C; q.x1_bstride = (int64_t)C * Pn;
+        q.wp = p.qkv_wp; q.bias = p.qkv_b;
+        q.ln_w = p.ln1_w; q.ln_b = p.ln1_b; q.ln_eps = 1e-5f;
+        q.out = bufA; q.out_bstride = (int64_t)3 * C * Pn; q.Cout = 3 * C; q.B = B; q.P = Pn; q.w = ww;
+        RF_TRY(launch_conv1x1(q, st));
+
+        DwConvArgs d{};
+        d.x = bufA; d.x_bstride = (int64_t)3 * C * Pn; d.out = bufB; d.out_bstride = (int64_t)3 * C * Pn;
+        d.w = p.qkv_dw_w; d.bias = p.qkv_dw_b;
+        d.B = B; d.C = 3 * C; d.h = hh; d.w_ = ww; d.gelu = 0;
+        RF_TRY(launch_dwconv3x3(d, st));
+
+        GramArgs g{};
+        g.q = bufB; g.k = bufB + (size_t)C * Pn; g.bstride = (int64_t)3 * C * Pn;
+        g.B = B; g.C = C; g.heads = heads; g.P = Pn; g.partial = partial;
+        size_t pf;
+        RF_TRY(gram_plan(B, C, heads, Pn, &g.nslab, &g.slab, &pf));
+        RF_TRY(launch_gram(g, st));
+        nslab = g.nslab;
+        av.x1 = bufB + (size_t)2 * C * Pn; av.x1_bstride = (int64_t)3 * C * Pn;
+    }
+    RF_TRY(launch_attn_fold(partial, nslab, p.temperature, p.proj_w, wfold, B, C, heads, st));
+    av.C1 = C;
+    av.wp = wfold; av.wp_bstride = (int64_t)packed1x1_floats(C, C);
+    av.bias = p.proj_b;
+    av.res = in; av.res_bstride = (int64_t)C * Pn;
+    av.out = x1; av.out_bstride = (int64_t)C * Pn; av.Cout = C; av.B = B; av.P = Pn; av.w = ww;
+    RF_TRY(launch_conv1x1(av, st));
+
+    // x + ffn(LN2(x)) ----------------------------------------------------------------------
+    if (!no_fuse && fused_ffn_supported(C, hc, hh, ww)) {
+        // LN2 -> 1x1 -> depthwise 3x3 -> GELU -> 1x1 + residual in one kernel: the hidden tensor stays on chip
+        RF_TRY(launch_ffn_fused(x1, out, p.ln2_w, p.ln2_b, p.pw1_wp, p.pw1_b, p.dw_w, p.dw_b, p.pw2_wp, p.pw2_b, B, C, hh, ww, st));
+    } else {
+        Conv1x1Args f1{};
+        f1.x1 = x1; f1.C1 = C; f1.x1_bstride = (int64_t)C * Pn;
+        f1.wp = p.pw1_wp; f1.bias = p.pw1_b;
+        f1.ln_w = p.ln2_w; f1.ln_b = p.ln2_b; f1.ln_eps = 1e-5f;
+        f1.out = bufA; f1.out_bstride = (int64_t)hc * Pn; f1.Cout = hc; f1.B = B; f1.P = Pn; f1.w = ww;
+        RF_TRY(launch_conv1x1(f1, st));
+
+        DwConvArgs d2{};
+        d2.x = bufA; d2.x_bstride = (int64_t)hc * Pn; d2.out = bufB; d2.out_bstride = (int64_t)hc * Pn;
+        d2.w = p.dw_w; d2.bias = p.dw_b;
+        d2.B = B; d2.C = hc; d2.h = hh; d2.w_ = ww; d2.gelu = 1;
+        RF_TRY(launch_dwconv3x3(d2, st));
+
+        Conv1x1Args f2{};
+        f2.x1 = bufB; f2.C1 = hc; f2.x1_bstride = (int64_t)hc * Pn;
+        f2.wp = p.pw2_wp; f2.bias = p.pw2_b;
+        f2.res = x1; f2.res_bstride = (int64_t)C * Pn;
+        f2.out = out; f2.out_bstride = (int64_t)C * Pn; f2.Cout = C; f2.B = B; f2.P = Pn; f2.w = ww;
+        RF_TRY(launch_conv1x1(f2, st));
+    }
+    return RF_OK;
+}
+
+}  // namespace rf

@@ -143,6 +143,17 @@ int fused_attn_plan(int h, int w, int* nslab, size_t* partial_floats, int B, int
 int launch_attn_front(const float* x, float* v, float* partial, int nslab, const float* ln_w, const float* ln_b,
                       const float* wp, const float* bq, const float* wd, const float* bd, int B, int C, int h, int w, hipStream_t st);
 
+// ---- TransformerBlock schedule (rf_block.hip)
+struct TbParams {
+    const float *ln1_w, *ln1_b, *temperature;
+    const float *qkv_wp /* packed */, *qkv_b, *qkv_dw_w, *qkv_dw_b, *proj_w /* raw [C][C] */, *proj_b;
+    const float *ln2_w, *ln2_b, *pw1_wp /* packed */, *pw1_b, *dw_w, *dw_b, *pw2_wp /* packed */, *pw2_b;
+};
+struct TbBufOffsets { size_t bufA, bufB, x1, partial, wfold; };   // float offsets into one scratch area
+size_t transformer_scratch_floats(int B, int C, int heads, int hc, int h, int w, TbBufOffsets* o);
+int run_transformer(const TbParams& p, const float* in, float* out, float* ws, const TbBufOffsets& o,
+                    int B, int C, int heads, int hc, int hh, int ww, hipStream_t st);
+
 // ---- FLCA (rf_flca.hip)
 size_t guidance_scratch_floats(int B, int H, int W);
 // packed-or-mosaic input -> base planes in scratch (y, cr, cb at HxW; LL, mag at H/2 x W/2)
@@ -157,6 +168,11 @@ struct FlcaSpatialArgs {
 };
 int flca_nblk(int h, int w);
 int launch_flca_spatial(const FlcaSpatialArgs& a, hipStream_t st);
+// squeeze-excite gate only: ch_out[b][c]
+int launch_flca_se(const float* partial, int nblk, int P, const float* se1_w, const float* se1_b,
+                   const float* se3_w, const float* se3_b, int hidden, float* ch_out, int B, int C, hipStream_t st);
+// x[b][c][:] *= ch[b][c]   (operator-level FLCA output; the forward folds the gate into the next 1x1 instead)
+int launch_scale_channels(float* x, const float* ch, int B, int C, int P, hipStream_t st);
 // SE + fold into channel_reduce: wp_out[b] = pack([Wa * diag(ch_b) | Wb])
 int launch_flca_se_fold(const float* partial, int nblk, int P, const float* se1_w, const float* se1_b,
                         const float* se3_w, const float* se3_b, int hidden, const float* w_cr,

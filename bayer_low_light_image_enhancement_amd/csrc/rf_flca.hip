@@ -356,12 +356,31 @@ __global__ void __launch_bounds__(256) flca_fold_kernel(const float* __restrict_
     }
 }
 
+int launch_flca_se(const float* partial, int nblk, int P, const float* se1_w, const float* se1_b,
+                   const float* se3_w, const float* se3_b, int hidden, float* ch_out, int B, int C, hipStream_t st) {
+    RF_CHECK_ARG(C <= 512 && hidden <= 64 && C % 8 == 0 && ch_out, "flca_se: C=%d hidden=%d unsupported", C, hidden);
+    flca_se_kernel<<<B, 256, 0, st>>>(partial, nblk, P, se1_w, se1_b, se3_w, se3_b, hidden, ch_out, C);
+    return check_launch("flca_se");
+}
+
+__global__ void __launch_bounds__(256) scale_channels_kernel(float* __restrict__ x, const float* __restrict__ ch, int P, size_t total) {
+    for (size_t i = blockIdx.x * 256ull + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) x[i] *= ch[i / P];
+}
+
+int launch_scale_channels(float* x, const float* ch, int B, int C, int P, hipStream_t st) {
+    const size_t total = (size_t)B * C * P;
+    int g = (int)((total + 255) / 256);
+    if (g > 4096) g = 4096;
+    scale_channels_kernel<<<g, 256, 0, st>>>(x, ch, P, total);
+    return check_launch("scale_channels");
+}
+
 int launch_flca_se_fold(const float* partial, int nblk, int P, const float* se1_w, const float* se1_b,
                         const float* se3_w, const float* se3_b, int hidden, const float* w_cr,
                         float* wp_out, float* ch_out, int B, int C, hipStream_t st) {
-    RF_CHECK_ARG(C <= 512 && hidden <= 64 && C % 8 == 0 && ch_out, "flca_se: C=%d hidden=%d unsupported", C, hidden);
     ProfScope prof(st, "flca_se_kernel+flca_fold_kernel", 0.0, 0.0);
-    flca_se_kernel<<<B, 256, 0, st>>>(partial, nblk, P, se1_w, se1_b, se3_w, se3_b, hidden, ch_out, C);
+    const int rc = launch_flca_se(partial, nblk, P, se1_w, se1_b, se3_w, se3_b, hidden, ch_out, B, C, st);
+    if (rc) return rc;
     int gx = cdiv(cdiv(C, 16) * (C / 2) * 64, 256 * 4);
     if (gx < 1) gx = 1;
     flca_fold_kernel<<<dim3((unsigned)gx, (unsigned)B), 256, 0, st>>>(w_cr, ch_out, wp_out, C);

@@ -191,85 +191,22 @@ int run_stage(const rf_handle* h, int i, int lvl, const float* in, float* out, f
     const int C = cfg.dim << lvl, hh = H >> lvl, ww = W >> lvl, Pn = hh * ww, heads = cfg.heads[lvl];
     const int hc = C * cfg.ffn_expansion;
     const std::string pre = "conv_tran" + std::to_string(i) + ".", t = pre + "Transformer.";
-    float* bufA = ws + p.bufA;
-    float* bufB = ws + p.bufB;
-    float* x1 = ws + p.x1;
     float* trans = ws + p.trans;
     float* xs = ws + p.xs;
     float* crb = ws + p.cr;
 
-    // x + attn(LN1(x)) ---------------------------------------------------------------------
-    const bool no_fuse = getenv("RF_NO_FUSE") != nullptr;   // diagnostic: force the op-by-op path
-    Conv1x1Args av{};
-    int nslab = 0;
-    if (!no_fuse && fused_attn_supported(C, heads, hh, ww)) {
-        // LN1 -> qkv 1x1 -> depthwise 3x3 -> {Gram partials, v} in one kernel: qkv never reaches HBM
-        size_t pf;
-        RF_TRY(fused_attn_plan(hh, ww, &nslab, &pf, B, C));
-        RF_TRY(launch_attn_front(in, bufB, ws + p.gram_partial, nslab, P(h, t + "norm1.body.weight"), P(h, t + "norm1.body.bias"),
-                                 PK(h, t + "attn.qkv.weight"), P(h, t + "attn.qkv.bias"), P(h, t + "attn.qkv_dwconv.weight"),
-                                 P(h, t + "attn.qkv_dwconv.bias"), B, C, hh, ww, st));
-        av.x1 = bufB; av.x1_bstride = (int64_t)C * Pn;
-    } else {
-        Conv1x1Args q{};
-        q.x1 = in; q.C1 = C; q.x1_bstride = (int64_t)C * Pn;
-        q.wp = PK(h, t + "attn.qkv.weight"); q.bias = P(h, t + "attn.qkv.bias");
-        q.ln_w = P(h, t + "norm1.body.weight"); q.ln_b = P(h, t + "norm1.body.bias"); q.ln_eps = 1e-5f;
-        q.out = bufA; q.out_bstride = (int64_t)3 * C * Pn; q.Cout = 3 * C; q.B = B; q.P = Pn; q.w = ww;
-        RF_TRY(launch_conv1x1(q, st));
-
-        DwConvArgs d{};
-        d.x = bufA; d.x_bstride = (int64_t)3 * C * Pn; d.out = bufB; d.out_bstride = (int64_t)3 * C * Pn;
-        d.w = P(h, t + "attn.qkv_dwconv.weight"); d.bias = P(h, t + "attn.qkv_dwconv.bias");
-        d.B = B; d.C = 3 * C; d.h = hh; d.w_ = ww; d.gelu = 0;
-        RF_TRY(launch_dwconv3x3(d, st));
-
-        GramArgs g{};
-        g.q = bufB; g.k = bufB + (size_t)C * Pn; g.bstride = (int64_t)3 * C * Pn;
-        g.B = B; g.C = C; g.heads = heads; g.P = Pn; g.partial = ws + p.gram_partial;
-        size_t pf;
-        RF_TRY(gram_plan(B, C, heads, Pn, &g.nslab, &g.slab, &pf));
-        RF_TRY(launch_gram(g, st));
-        nslab = g.nslab;
-        av.x1 = bufB + (size_t)2 * C * Pn; av.x1_bstride = (int64_t)3 * C * Pn;
-    }
-    RF_TRY(launch_attn_fold(ws + p.gram_partial, nslab, P(h, t + "attn.temperature"), P(h, t + "attn.project_out.weight"),
-                            ws + p.wfold_attn, B, C, heads, st));
-    av.C1 = C;
-    av.wp = ws + p.wfold_attn; av.wp_bstride = (int64_t)packed1x1_floats(C, C);
-    av.bias = P(h, t + "attn.project_out.bias");
-    av.res = in; av.res_bstride = (int64_t)C * Pn;
-    av.out = x1; av.out_bstride = (int64_t)C * Pn; av.Cout = C; av.B = B; av.P = Pn; av.w = ww;
-    RF_TRY(launch_conv1x1(av, st));
-
-    // x + ffn(LN2(x)) ----------------------------------------------------------------------
-    if (!no_fuse && fused_ffn_supported(C, hc, hh, ww)) {
-        // LN2 -> 1x1 -> depthwise 3x3 -> GELU -> 1x1 + residual in one kernel: the hidden tensor stays on chip
-        RF_TRY(launch_ffn_fused(x1, trans, P(h, t + "norm2.body.weight"), P(h, t + "norm2.body.bias"),
-                                PK(h, t + "ffn.pointwise1.weight"), P(h, t + "ffn.pointwise1.bias"),
-                                P(h, t + "ffn.depthwise.weight"), P(h, t + "ffn.depthwise.bias"),
-                                PK(h, t + "ffn.pointwise2.weight"), P(h, t + "ffn.pointwise2.bias"), B, C, hh, ww, st));
-    } else {
-        Conv1x1Args f1{};
-        f1.x1 = x1; f1.C1 = C; f1.x1_bstride = (int64_t)C * Pn;
-        f1.wp = PK(h, t + "ffn.pointwise1.weight"); f1.bias = P(h, t + "ffn.pointwise1.bias");
-        f1.ln_w = P(h, t + "norm2.body.weight"); f1.ln_b = P(h, t + "norm2.body.bias"); f1.ln_eps = 1e-5f;
-        f1.out = bufA; f1.out_bstride = (int64_t)hc * Pn; f1.Cout = hc; f1.B = B; f1.P = Pn; f1.w = ww;
-        RF_TRY(launch_conv1x1(f1, st));
-
-        DwConvArgs d2{};
-        d2.x = bufA; d2.x_bstride = (int64_t)hc * Pn; d2.out = bufB; d2.out_bstride = (int64_t)hc * Pn;
-        d2.w = P(h, t + "ffn.depthwise.weight"); d2.bias = P(h, t + "ffn.depthwise.bias");
-        d2.B = B; d2.C = hc; d2.h = hh; d2.w_ = ww; d2.gelu = 1;
-        RF_TRY(launch_dwconv3x3(d2, st));
-
-        Conv1x1Args f2{};
-        f2.x1 = bufB; f2.C1 = hc; f2.x1_bstride = (int64_t)hc * Pn;
-        f2.wp = PK(h, t + "ffn.pointwise2.weight"); f2.bias = P(h, t + "ffn.pointwise2.bias");
-        f2.res = x1; f2.res_bstride = (int64_t)C * Pn;
-        f2.out = trans; f2.out_bstride = (int64_t)C * Pn; f2.Cout = C; f2.B = B; f2.P = Pn; f2.w = ww;
-        RF_TRY(launch_conv1x1(f2, st));
-    }
+    // TransformerBlock: x + attn(LN1(x)), then x + ffn(LN2(x))  (rf_block.hip)
+    TbParams tp{};
+    tp.ln1_w = P(h, t + "norm1.body.weight"); tp.ln1_b = P(h, t + "norm1.body.bias"); tp.temperature = P(h, t + "attn.temperature");
+    tp.qkv_wp = PK(h, t + "attn.qkv.weight"); tp.qkv_b = P(h, t + "attn.qkv.bias");
+    tp.qkv_dw_w = P(h, t + "attn.qkv_dwconv.weight"); tp.qkv_dw_b = P(h, t + "attn.qkv_dwconv.bias");
+    tp.proj_w = P(h, t + "attn.project_out.weight"); tp.proj_b = P(h, t + "attn.project_out.bias");
+    tp.ln2_w = P(h, t + "norm2.body.weight"); tp.ln2_b = P(h, t + "norm2.body.bias");
+    tp.pw1_wp = PK(h, t + "ffn.pointwise1.weight"); tp.pw1_b = P(h, t + "ffn.pointwise1.bias");
+    tp.dw_w = P(h, t + "ffn.depthwise.weight"); tp.dw_b = P(h, t + "ffn.depthwise.bias");
+    tp.pw2_wp = PK(h, t + "ffn.pointwise2.weight"); tp.pw2_b = P(h, t + "ffn.pointwise2.bias");
+    TbBufOffsets to{p.bufA, p.bufB, p.x1, p.gram_partial, p.wfold_attn};
+    RF_TRY(run_transformer(tp, in, trans, ws, to, B, C, heads, hc, hh, ww, st));
 
     // branch, cat, channel_reduce -------------------------------------------------------------
     Conv1x1Args r{};

@@ -267,3 +267,52 @@ def flca_guidance(x4: torch.Tensor, size: Tuple[int, int]) -> torch.Tensor:
     with torch.cuda.device(x4.device):
         _lib.check(lib.rf_flca_guidance(_ptr(x4), _ptr(out), _ptr(scratch), b, h, w, size[0], size[1], _stream(x4)), "rf_flca_guidance")
     return out
+
+
+_TB_KEYS = ("norm1.body.weight", "norm1.body.bias", "attn.temperature", "attn.qkv.weight", "attn.qkv.bias",
+            "attn.qkv_dwconv.weight", "attn.qkv_dwconv.bias", "attn.project_out.weight", "attn.project_out.bias",
+            "norm2.body.weight", "norm2.body.bias", "ffn.pointwise1.weight", "ffn.pointwise1.bias",
+            "ffn.depthwise.weight", "ffn.depthwise.bias", "ffn.pointwise2.weight", "ffn.pointwise2.bias")
+
+
+def transformer_block(x: torch.Tensor, params, heads: int, ffn_expansion_factor: int = 2, prefix: str = "") -> torch.Tensor:
+    """``TransformerBlock(dim, heads, ffn_expansion_factor, bias=True)(x)``
+    (FrequencyawareLumaChromaAttentionRAWFormer.py:238-254).  ``params`` maps the block's
+    state_dict keys (``norm1.body.weight`` ...) to device tensors.  Same schedule as the whole
+    forward, i.e. the fused gfx950 kernels where the shape allows."""
+    x = _chk(x, "x")
+    b, c, h, w = x.shape
+    ts = [_chk(params[prefix + k], k) for k in _TB_KEYS]
+    lib = _lib.load()
+    sz = C.c_size_t()
+    _lib.check(lib.rf_transformer_block_scratch_bytes(b, c, heads, ffn_expansion_factor, h, w, C.byref(sz)),
+               "rf_transformer_block_scratch_bytes")
+    scratch = _scratch(sz.value, x)
+    out = torch.empty_like(x)
+    ptrs = (C.c_void_p * len(ts))(*[t.data_ptr() for t in ts])
+    with torch.cuda.device(x.device):
+        _lib.check(lib.rf_transformer_block(_ptr(x), _ptr(out), ptrs, _ptr(scratch), b, c, heads, ffn_expansion_factor, h, w,
+                                            _stream(x)), "rf_transformer_block")
+    return out
+
+
+_FLCA_KEYS = ("alpha", "beta", "gamma", "low_attn.0.weight", "high_attn.0.weight", "chroma_attn.0.weight",
+              "se.1.weight", "se.1.bias", "se.3.weight", "se.3.bias")
+
+
+def flca(feat: torch.Tensor, x4: torch.Tensor, params, prefix: str = "") -> torch.Tensor:
+    """``FLCA(channels)(feat, *BayerLumaChroma()(x4))`` (FrequencyawareLumaChromaAttentionRAWFormer.py:103-162):
+    guidance from the packed RGGB frame ``x4``, spatial gates, squeeze-excite."""
+    feat = _chk(feat, "feat")
+    b, c, h, w = feat.shape
+    guide = flca_guidance(x4, (h, w))
+    ts = [_chk(params[prefix + k].reshape(-1) if params[prefix + k].dim() == 0 else params[prefix + k], k) for k in _FLCA_KEYS]
+    lib = _lib.load()
+    sz = C.c_size_t()
+    _lib.check(lib.rf_flca_scratch_bytes(b, c, h, w, C.byref(sz)), "rf_flca_scratch_bytes")
+    scratch = _scratch(sz.value, feat)
+    out = torch.empty_like(feat)
+    ptrs = (C.c_void_p * len(ts))(*[t.data_ptr() for t in ts])
+    with torch.cuda.device(feat.device):
+        _lib.check(lib.rf_flca(_ptr(feat), _ptr(guide), _ptr(out), ptrs, _ptr(scratch), b, c, h, w, _stream(feat)), "rf_flca")
+    return out

@@ -130,6 +130,20 @@ int rf_chan_attn(const float* in, float* out, const float* qkv_w, const float* q
                  const float* dw_w, const float* dw_b, const float* temperature,
                  const float* proj_w, const float* proj_b, void* scratch,
                  int B, int C, int heads, int h, int w, void* stream);
+/* TransformerBlock.forward: FrequencyawareLumaChromaAttentionRAWFormer.py:238-254 (model.py:81-92).
+ * prm = HOST array of 17 device pointers in state_dict order: norm1.{w,b}, attn.temperature,
+ * attn.qkv.{w,b}, attn.qkv_dwconv.{w,b}, attn.project_out.{w,b}, norm2.{w,b},
+ * ffn.pointwise1.{w,b}, ffn.depthwise.{w,b}, ffn.pointwise2.{w,b}.  Uses the fused gfx950 kernels
+ * (rf_fused.hip) where the shape allows, exactly as rf_forward does. */
+int rf_transformer_block_scratch_bytes(int B, int C, int heads, int ffn_expansion, int h, int w, size_t* bytes);
+int rf_transformer_block(const float* in, float* out, const float* const* prm, void* scratch,
+                         int B, int C, int heads, int ffn_expansion, int h, int w, void* stream);
+/* FLCA.forward given the guidance planes: FrequencyawareLumaChromaAttentionRAWFormer.py:134-162.
+ * guide = [B,4,h,w] from rf_flca_guidance at the feature size; prm = HOST array of 10 device pointers:
+ * alpha, beta, gamma, low_attn.0.w, high_attn.0.w, chroma_attn.0.w, se.1.{w,b}, se.3.{w,b}. */
+int rf_flca_scratch_bytes(int B, int C, int h, int w, size_t* bytes);
+int rf_flca(const float* feat, const float* guide, float* out, const float* const* prm, void* scratch,
+            int B, int C, int h, int w, void* stream);
 /* BayerLumaChroma + HaarDWT + bilinear resize = the guidance planes of FLCA
  * (FrequencyawareLumaChromaAttentionRAWFormer.py:79-97,138-149).
  * packed [B,4,H,W] -> guide [B,4,hf,wf] = (y_low, y_high, cr, cb); scratch >= rf_guidance_scratch_bytes. */

@@ -224,3 +224,30 @@ def test_flca_guidance(ops, device):
     y, cr, cb = R.bayer_luma_chroma(x4)
     for size in ((32, 48), (16, 24), (8, 12), (4, 6)):
         close(ops.flca_guidance(x4.to(device), size), R.flca_guidance(y, cr, cb, size), 2e-6)
+
+
+@pytest.mark.parametrize("c,hw", cases.ATTN_CASES)
+def test_transformer_block_golden(ops, g, device, c, hw):
+    """a7: the reference's TransformerBlock outputs; c = 32 runs the fused attention-front / FFN kernels."""
+    p = dev(params(cases.transformer_spec(c)), device)
+    out = ops.transformer_block(rnd(f"x.attn{c}", (2, c) + hw).to(device), p, heads=8)
+    close(out, g[f"transformer_c{c}"])
+
+
+@pytest.mark.parametrize("c,heads,hw", [(32, 8, (64, 64)), (32, 8, (20, 72)), (32, 4, (8, 132)), (64, 8, (32, 32)), (32, 2, (12, 8))])
+def test_transformer_block_oracle(ops, device, c, heads, hw):
+    """Fused kernels on partial tiles (heights / widths that are not multiples of the 4x64 tile)."""
+    spec = cases.transformer_spec(c)
+    spec["attn.temperature"] = (heads, 1, 1)
+    p = params(spec)
+    x = rnd("tb.x", (2, c) + hw)
+    ref = R.transformer_block(x, p, "", heads)
+    close(ops.transformer_block(x.to(device), dev(p, device), heads=heads), ref)
+
+
+def test_flca_golden(ops, g, device):
+    x4 = rnd("x.packed", (2, 4, 32, 48), 0, 1).to(device)
+    for c, hw in cases.FLCA_CASES:
+        p = dev(params(cases.flca_spec(c)), device)
+        out = ops.flca(rnd(f"x.flca{c}", (2, c) + hw).to(device), x4, p)
+        close(out, g[f"flca_c{c}"])
