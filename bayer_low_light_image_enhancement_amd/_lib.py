@@ -62,6 +62,9 @@ SIGNATURES = {
     "rf_flca": (_i, [_vp, _vp, _vp, C.POINTER(_vp), _vp, _i, _i, _i, _i, _vp]),
     "rf_guidance_scratch_bytes": (_i, [_i, _i, _i, _psz]),
     "rf_flca_guidance": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
+    "rf_to_uint8_hwc": (_i, [_vp, _vp, _i, _i, _i, _i, _vp]),
+    "rf_u8_sse": (_i, [_vp, _vp, _vp, _i, _sz, _vp]),
+    "rf_u8_channel_sums": (_i, [_vp, _vp, _i, _i, _sz, _vp]),
 }
 
 _lib = None

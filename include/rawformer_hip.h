@@ -150,6 +150,15 @@ int rf_flca(const float* feat, const float* guide, float* out, const float* cons
 int rf_guidance_scratch_bytes(int B, int H, int W, size_t* bytes);
 int rf_flca_guidance(const float* packed, float* guide, void* scratch, int B, int H, int W, int hf, int wf, void* stream);
 
+/* ---- evaluation harness: test.py:117-124 on the device ----------- */
+/* (clamp(pred,0,1) * 255).astype(uint8), CHW float32 -> HWC uint8 (truncation): test.py:117-118 */
+int rf_to_uint8_hwc(const float* in, unsigned char* out, int B, int C, int h, int w, void* stream);
+/* per-image sum of squared differences of two uint8 images, exact uint64: PSNR (test.py:123) =
+ * 10 log10(255^2 * n_per_image / sse) */
+int rf_u8_sse(const unsigned char* a, const unsigned char* b, unsigned long long* sse, int B, size_t n_per_image, void* stream);
+/* per-image, per-channel sums of HWC uint8 images (auto_correct_rb compares channel means, test.py:31-40) */
+int rf_u8_channel_sums(const unsigned char* a, unsigned long long* sums, int B, int C, size_t hw, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -307,6 +307,29 @@ def config4(flca_mod):
          in_checksum=checksum(x))
 
 
+def harness():
+    """test.py's helpers cannot be imported (module-level ``from skimage...``); the two pure-numpy
+    functions are executed from their source text (test.py:17-40), the uint8 conversion is the
+    expression of test.py:118 evaluated by numpy here."""
+    src = open(os.path.join(REF, "test.py")).read()
+    seg = src[src.index("def correct_bayer_channels"):src.index("# ------------------------------\n# Main testing pipeline")]
+    ns = {"np": np}
+    exec(compile(seg, "test.py#helpers", "exec"), ns)
+    out = {}
+    for i, (hh, ww) in enumerate(((6, 8), (5, 7), (16, 16))):
+        pred = synth.uniform(31 + i, "harness.pred", (3, hh, ww), -0.2, 1.3)      # exercises both clamps
+        u8 = (np.clip(pred, 0, 1).transpose(1, 2, 0) * 255).astype(np.uint8)     # test.py:117-118
+        out[f"pred{i}"] = pred
+        out[f"u8_{i}"] = u8
+        for pat in ("RGGB", "BGGR", "GBRG", "GRBG"):
+            out[f"bayer_{pat}_{i}"] = np.ascontiguousarray(ns["correct_bayer_channels"](u8, pat))
+        out[f"auto_{i}"] = np.ascontiguousarray(ns["auto_correct_rb"](u8))
+        dark_red = u8.copy()
+        dark_red[..., 0] //= 4
+        out[f"auto_darkred_{i}"] = np.ascontiguousarray(ns["auto_correct_rb"](dark_red))
+    save("harness", **out)
+
+
 def state_dict_keys(flca_mod):
     """Key names and shapes of the reference's state_dict (what test.py:88-91 loads strictly)."""
     import json
@@ -324,11 +347,16 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--big", action="store_true", help="also run BASELINE configs 2-3 (minutes of CPU)")
     ap.add_argument("--only-keys", action="store_true", help="only (re)write state_dict_keys.json")
+    ap.add_argument("--only-harness", action="store_true", help="only the evaluation-harness fixture (test.py helpers)")
     ap.add_argument("--only-cfg4", action="store_true", help="only BASELINE config 4 (RawFormer-L, one 2848x4256 mosaic)")
     args = ap.parse_args()
     if args.only_keys:
         os.makedirs(GOLD, exist_ok=True)
         state_dict_keys(import_reference()[0])
+        return
+    if args.only_harness:
+        os.makedirs(GOLD, exist_ok=True)
+        harness()
         return
     if args.only_cfg4:
         torch.set_num_threads(8)
