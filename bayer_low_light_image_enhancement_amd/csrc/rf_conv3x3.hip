@@ -2,7 +2,7 @@
 // (v_mfma_f32_16x16x4_f32; K = 4 input channels at one tap per instruction).
 //
 // Workgroup = 4 waves; it owns a (4*RW rows) x (64/RW cols) pixel tile and NCO*16 output
-// channels.  Per 8-input-channel chunk the halo'd input tile and the matching slice of the
+// channels, and is persistent over several such tiles.  Per 8-input-channel chunk the halo'd input tile and the matching slice of the
 // lane-ordered packed weights sit in LDS; every wave then walks 2 k-sets x 9 taps.
 //   * B operand: lane (kq, j) owns 4 consecutive pixels of one row.  Two ds_read_b128 per
 //     (k-set, dy) fetch the 6 neighbours those pixels need; tap dx of pixel g is v[g + dx], so
@@ -23,15 +23,16 @@
 namespace rf {
 
 static constexpr int KC = 8;        // input channels per LDS chunk
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 
 template <int NCO, int LOG2_RW, int RPW>
-__global__ void __launch_bounds__(256, 2) conv3x3_kernel(Conv3x3Args a, int ngroups, int tiles_x, int vec) {
+__global__ void __launch_bounds__(256, 2) conv3x3_kernel(Conv3x3Args a, int ngroups, int tiles_x, int ntiles, int vec) {
     constexpr int RW = 1 << LOG2_RW;         // rows one MFMA pixel group spans (narrow images)
     constexpr int TW = 64 / RW;              // tile width
-    constexpr int TH = 4 * RW * RPW;         // tile height: every wave owns RPW row groups (RPW = 2 for few output
-                                             // channels: twice the MFMAs per staged weight, 25 % less halo)
-    constexpr int RS = TW + 8;               // LDS row stride
+    constexpr int TH = 4 * RW * RPW;         // tile height: a wave owns RPW row groups (RPW = 2 for few output channels:
+                                             // twice the MFMAs per barrier and per staged weight, 17 % less halo)
     static_assert(RPW == 1 || RW == 1, "two row groups per wave only with one row per group");
+    constexpr int RS = TW + 8;               // LDS row stride
     constexpr int PS = ((TH + 2) * RS + 63) / 64 * 64;   // LDS plane stride in floats (multiple of 64)
     constexpr int NIN = KC * (TH + 2) * (TW + 2);       // staged input elements per chunk
     constexpr int EPT = (NIN + 255) / 256;              // ... per thread
@@ -45,66 +46,97 @@ __global__ void __launch_bounds__(256, 2) conv3x3_kernel(Conv3x3Args a, int ngro
     const int j = lane & 15, kq = lane >> 4;
     const int rowj = j / (16 / RW), cg = j % (16 / RW);
     const int grp = blockIdx.x % ngroups;
-    const int tile = blockIdx.x / ngroups;
-    const int tx = tile % tiles_x, ty = tile / tiles_x;
+    const int wg = blockIdx.x / ngroups;
     const int b = blockIdx.y;
     const int h = a.h, w = a.w;
-    const int x0 = tx * TW, y0 = ty * TH;
     const int NT = (a.Cout + 15) >> 4;
     const int t0 = grp * NCO;
     const int nchunks = (a.Cin + KC - 1) / KC;
     const float* xb = a.x + (size_t)b * a.x_bstride;
     const size_t chunk_stride = a.unshuffle_in ? (size_t)(KC / 4) * 4 * h * w : (size_t)KC * h * w;
 
-    // ---- per-thread gather plan for the input tile (same for every chunk up to the channel base)
-    int goff[EPT];        // offset inside the chunk's KC planes, or -1 = zero padding / beyond the tile
-    short loff[EPT];      // LDS offset inside the buffer
-    short gcl[EPT];       // channel inside the chunk
+    // ---- staging plan.  Every per-chunk instruction of the staging path is a memory instruction with
+    // precomputed operands: f32 MFMA time and VALU time add up on this hardware (measured: ~250 VALU per
+    // chunk cost 10 %), so the chunk loop carries no address arithmetic, selects or masks.
+    //   * input: buffer_load_dword through a per-chunk descriptor (base = first plane of the chunk,
+    //     num_records = the planes that exist).  Zero padding, "no element" and channels beyond Cin
+    //     are out-of-range offsets -> the hardware returns 0.
+    //   * weights: buffer_load_dwordx4, same trick for output tiles beyond Cout.
+    // Element i of this thread is halo'd-tile element idx = tid + 256 i = (channel cl, row r, col c).
+    constexpr unsigned OOB = 0x80000000u;   // > any num_records (images are < 2 GiB, checked by the launcher)
+    int prc[EPT];             // (cl << 16) | (r << 8) | c, or -1 = no element
+    short loff[EPT];          // LDS float offset inside a buffer ("no element" -> a spare slot in the plane padding,
+                              // so the LDS writes need no predicate; 128 spare slots, 2 threads of different waves each)
+    static_assert(PS - (TH + 2) * RS >= 16, "plane padding holds the dummy slots");
+    const int dummy = (tid & 7) * PS + (TH + 2) * RS + ((tid >> 3) & 15);
 #pragma unroll
     for (int i = 0; i < EPT; ++i) {
         const int idx = tid + 256 * i;
         const int c = idx % (TW + 2);
         const int r = (idx / (TW + 2)) % (TH + 2);
         const int cl = idx / ((TW + 2) * (TH + 2));
-        const int y = y0 - 1 + r, x = x0 - 1 + c;
-        const bool ok = idx < NIN && y >= 0 && y < h && x >= 0 && x < w;
-        int off;
-        if (a.unshuffle_in)   // packed channel cl = 2*i + jj of mosaic plane 0 lives at (2y+i, 2x+jj); KC = 8 covers 2 planes
-            off = ((cl >> 2) * 2 * h + 2 * y + ((cl >> 1) & 1)) * (2 * w) + 2 * x + (cl & 1);
-        else
-            off = (cl * h + y) * w + x;
-        goff[i] = ok ? off : -1;
-        loff[i] = (short)(idx < NIN ? cl * PS + r * RS + c : -1);
-        gcl[i] = (short)cl;
+        prc[i] = idx < NIN ? (cl << 16) | (r << 8) | c : -1;
+        loff[i] = (short)(idx < NIN ? cl * PS + r * RS + c : dummy);
     }
+    unsigned wvoff[WPT];      // weight byte offsets inside one chunk's packed slice
+#pragma unroll
+    for (int i = 0; i < WPT; ++i) {
+        const int idx = tid + 256 * i;
+        const int l4 = idx % 16;
+        const int t = (idx / 16) % NCO;
+        const int kt = idx / (16 * NCO);          // ks * 9 + tap
+        const bool ok = idx < NW4 && t0 + t < NT;
+        wvoff[i] = ok ? (unsigned)(((kt * NT + t0 + t) * 64 + l4 * 4) * 4) : OOB;
+    }
+    const int w_chunk_bytes = 2 * 9 * NT * 64 * 4;
+    const size_t plane_bytes = (size_t)h * w * 4;      // one packed-resolution plane
+
+    unsigned voff[EPT];       // current tile: byte offset inside the chunk's planes, OOB = zero
+    int x0 = 0, y0 = 0;       // origin of the tile the plan (and the loads in flight) belong to
+    auto plan_tile = [&](int tile) {
+        const int tx = tile % tiles_x, ty = tile / tiles_x;
+        x0 = tx * TW;
+        y0 = ty * TH;
+#pragma unroll
+        for (int i = 0; i < EPT; ++i) {
+            int e = prc[i];
+            asm volatile("" : "+v"(e));   // opaque: nothing derived from the element id stays live across the MFMA blocks
+            const int cl = e >> 16;
+            const int y = y0 - 1 + ((e >> 8) & 255), x = x0 - 1 + (e & 255);
+            const bool ok = e >= 0 && (unsigned)y < (unsigned)h && (unsigned)x < (unsigned)w;
+            // packed channel cl = 2*i + jj of mosaic plane 0 lives at (2y+i, 2x+jj); KC = 8 covers 2 mosaic planes
+            const int off_m = ((cl >> 2) * 2 * h + 2 * y + ((cl >> 1) & 1)) * (2 * w) + 2 * x + (cl & 1);
+            const int off_p = (cl * h + y) * w + x;
+            voff[i] = ok ? (unsigned)(4 * (a.unshuffle_in ? off_m : off_p)) : OOB;
+        }
+    };
     float xin[EPT];
     float4 win[WPT];
     auto load_chunk = [&](int ch) {
+        // planes of this chunk that exist: min(KC, Cin - ch*KC) channel planes (mosaic input: 4 channels = 1 plane of 4hw)
+        const int cl_lim = min(KC, a.Cin - ch * KC);
         const float* src = xb + (size_t)ch * chunk_stride;
+        const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(
+            const_cast<float*>(src), 0, (int)(a.unshuffle_in ? (size_t)(cl_lim / 4) * 4 * plane_bytes : (size_t)cl_lim * plane_bytes), 0x00020000);
+        const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc(
+            const_cast<float*>(a.wp) + (size_t)ch * (w_chunk_bytes / 4), 0, w_chunk_bytes, 0x00020000);
 #pragma unroll
-        for (int i = 0; i < EPT; ++i) {
-            const bool ok = goff[i] >= 0 && ch * KC + gcl[i] < a.Cin;
-            float v = src[ok ? goff[i] : 0];          // branch-free: clamped address, value masked below
-            if (a.clamp_in) v = fminf(fmaxf(v, 0.f), 1.f);
-            xin[i] = ok ? v : 0.f;
-        }
+        for (int i = 0; i < EPT; ++i) xin[i] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rx, (int)voff[i], 0, 0));
 #pragma unroll
         for (int i = 0; i < WPT; ++i) {
-            const int idx = tid + 256 * i;
-            const int l4 = idx % 16;
-            const int t = (idx / 16) % NCO;
-            const int kt = idx / (16 * NCO);          // ks * 9 + tap
-            const bool ok = idx < NW4 && t0 + t < NT;
-            const float4 v = *reinterpret_cast<const float4*>(a.wp + (((size_t)(ch * 2) * 9 + (ok ? kt : 0)) * NT + t0 + (ok ? t : 0)) * 64 + l4 * 4);
-            win[i] = ok ? v : make_float4(0.f, 0.f, 0.f, 0.f);
+            const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rw, (int)wvoff[i], 0, 0);
+            win[i] = make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w));
         }
     };
     auto store_chunk = [&](int buf) {
         float* li = lds + buf * BUF;
         float* lw = li + KC * PS;
 #pragma unroll
-        for (int i = 0; i < EPT; ++i)
-            if (loff[i] >= 0) li[loff[i]] = xin[i];
+        for (int i = 0; i < EPT; ++i) {
+            float v = xin[i];
+            if (a.clamp_in) v = fminf(fmaxf(v, 0.f), 1.f);      // uniform; only the clamp_io embedding conv
+            li[loff[i]] = v;
+        }
 #pragma unroll
         for (int i = 0; i < WPT; ++i) {
             const int idx = tid + 256 * i;
@@ -113,56 +145,77 @@ __global__ void __launch_bounds__(256, 2) conv3x3_kernel(Conv3x3Args a, int ngro
     };
 
     f32x4 acc[RPW][NCO][4];
-#pragma unroll
-    for (int rr = 0; rr < RPW; ++rr)
-#pragma unroll
-        for (int t = 0; t < NCO; ++t)
-#pragma unroll
-            for (int g = 0; g < 4; ++g) acc[rr][t][g] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
+    // ---- persistent over a contiguous range of tiles: the first chunk of the next tile is prefetched
+    // behind the last MFMA block of the current one, so only the very first load is exposed
+    // (tiles wg, wg + nwg, ...: the workgroups running at one time cover a compact band of the image that moves
+    // down it -- contiguous runs per workgroup put them 8 rows x 2^k bytes apart and lost 10 % at 512 x 512)
+    const int nwg = gridDim.x / ngroups;
+    int tile = wg;
+    const int tile_end = ntiles;
+    if (tile >= tile_end) return;
+    plan_tile(tile);
     load_chunk(0);
     store_chunk(0);
     __syncthreads();
-    for (int ch = 0; ch < nchunks; ++ch) {
-        if (ch + 1 < nchunks) load_chunk(ch + 1);       // in flight during the MFMA block below
-        const float* lds_in = lds + (ch & 1) * BUF;
-        const float* lds_w = lds_in + KC * PS;
+    int buf = 0;
+    float* outb = a.out + (size_t)b * a.out_bstride;
+    for (; tile < tile_end; tile += nwg) {
+        const int ex0 = x0, ey0 = y0;                  // this tile's origin (the plan moves on before the epilogue)
 #pragma unroll
-        for (int ks = 0; ks < 2; ++ks) {
-            const float* lp = lds_in + (ks * 4 + kq) * PS + (wave * RW * RPW + rowj) * RS + 4 * cg;
+        for (int rr = 0; rr < RPW; ++rr)
 #pragma unroll
-            for (int ir = 0; ir < RPW + 2; ++ir) {          // input row group ir feeds output row groups ir-2 .. ir
-                const float4 lo = *reinterpret_cast<const float4*>(lp + ir * RS);
-                const float4 hi = *reinterpret_cast<const float4*>(lp + ir * RS + 4);
-                const float v[6] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y};
+            for (int t = 0; t < NCO; ++t)
 #pragma unroll
-                for (int rr = 0; rr < RPW; ++rr) {
-                    const int dy = ir - rr;
-                    if (dy < 0 || dy > 2) continue;
+                for (int g = 0; g < 4; ++g) acc[rr][t][g] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        for (int ch = 0; ch < nchunks; ++ch) {
+            const bool last = ch + 1 == nchunks;
+            const bool more = !last || tile + nwg < tile_end;
+            const int nch = last ? 0 : ch + 1;
+            if (last && more) plan_tile(tile + nwg);
+            if (more) load_chunk(nch);                  // in flight during the MFMA block below
+            const float* lds_in = lds + buf * BUF;
+            const float* lds_w = lds_in + KC * PS;
+            const int nks = (a.Cin - ch * KC > 4) ? 2 : 1;   // a 4-channel tail (the embedding conv) skips the empty k-set
 #pragma unroll
-                    for (int dx = 0; dx < 3; ++dx) {
-                        const float* wl = lds_w + ((ks * 9 + dy * 3 + dx) * NCO) * 64 + lane;
+            for (int ks = 0; ks < 2; ++ks) {
+                if (ks >= nks) break;
+                const float* lp = lds_in + (ks * 4 + kq) * PS + (wave * RW * RPW + rowj) * RS + 4 * cg;
 #pragma unroll
-                        for (int t = 0; t < NCO; ++t) {
-                            const float av = wl[t * 64];
+                for (int ir = 0; ir < RPW + 2; ++ir) {          // input row group ir feeds output row groups ir-2 .. ir
+                    const float4 lo = *reinterpret_cast<const float4*>(lp + ir * RS);
+                    const float4 hi = *reinterpret_cast<const float4*>(lp + ir * RS + 4);
+                    const float v[6] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y};
 #pragma unroll
-                            for (int g = 0; g < 4; ++g)
-                                acc[rr][t][g] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, v[g + dx], acc[rr][t][g], 0, 0, 0);
+                    for (int rr = 0; rr < RPW; ++rr) {
+                        const int dy = ir - rr;
+                        if (dy < 0 || dy > 2) continue;
+#pragma unroll
+                        for (int dx = 0; dx < 3; ++dx) {
+                            const float* wl = lds_w + ((ks * 9 + dy * 3 + dx) * NCO) * 64 + lane;
+#pragma unroll
+                            for (int t = 0; t < NCO; ++t) {
+                                const float av = wl[t * 64];
+#pragma unroll
+                                for (int g = 0; g < 4; ++g)
+                                    acc[rr][t][g] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, v[g + dx], acc[rr][t][g], 0, 0, 0);
+                            }
                         }
                     }
                 }
             }
+            if (more) store_chunk(buf ^ 1);             // the other buffer: last read one barrier ago
+            __syncthreads();
+            buf ^= 1;
         }
-        if (ch + 1 < nchunks) store_chunk((ch + 1) & 1);   // the other buffer: last read one barrier ago
-        __syncthreads();
-    }
 
-    // ---- epilogue
-    float* outb = a.out + (size_t)b * a.out_bstride;
-    const int x = x0 + 4 * cg;
+    // ---- epilogue of this tile (its stores drain behind the next tile's first MFMA block)
+    int kq_ = kq;                      // opaque per tile: keeps the bias values and output row pointers from being
+    asm volatile("" : "+v"(kq_));      // hoisted out of the tile loop (they would stay live across every MFMA block)
+    const int x = ex0 + 4 * cg;
 #pragma unroll
     for (int rr = 0; rr < RPW; ++rr) {
-    const int y = y0 + (wave * RPW + rr) * RW + rowj;
+    const int y = ey0 + (wave * RPW + rr) * RW + rowj;
     if (y >= h || x >= w) continue;
 #pragma unroll
     for (int t = 0; t < NCO; ++t) {
@@ -170,7 +223,7 @@ __global__ void __launch_bounds__(256, 2) conv3x3_kernel(Conv3x3Args a, int ngro
         float v[4][4];   // [r][g]
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-            const int co = 16 * (t0 + t) + 4 * kq + r;
+            const int co = 16 * (t0 + t) + 4 * kq_ + r;
             const float bs = (a.bias && co < a.Cout) ? a.bias[co] : 0.f;
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
@@ -180,7 +233,7 @@ __global__ void __launch_bounds__(256, 2) conv3x3_kernel(Conv3x3Args a, int ngro
                 v[r][g] = u;
             }
         }
-        const int cobase = 16 * (t0 + t) + 4 * kq;
+        const int cobase = 16 * (t0 + t) + 4 * kq_;
         if (a.store == 0) {
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
@@ -238,22 +291,33 @@ __global__ void __launch_bounds__(256, 2) conv3x3_kernel(Conv3x3Args a, int ngro
         }
     }
     }
+    }
 }
 
 template <int NCO>
 static void launch_rw(const Conv3x3Args& a, int ngroups, int vec, hipStream_t st) {
-    // pick the tile shape from the image width: 64x4, 32x8 or 16x16 pixels
-    if (a.w > 32) {
-        // (two row groups per wave, RPW = 2, was measured for NCO <= 2: no gain -- 231 VGPRs -- so RPW = 1 everywhere)
-        const int txs = cdiv(a.w, 64), tys = cdiv(a.h, 4);
-        conv3x3_kernel<NCO, 0, 1><<<dim3((unsigned)(ngroups * txs * tys), (unsigned)a.B), 256, 0, st>>>(a, ngroups, txs, vec);
-    } else if (a.w > 16) {
-        const int txs = cdiv(a.w, 32), tys = cdiv(a.h, 8);
-        conv3x3_kernel<NCO, 1, 1><<<dim3((unsigned)(ngroups * txs * tys), (unsigned)a.B), 256, 0, st>>>(a, ngroups, txs, vec);
-    } else {
-        const int txs = cdiv(a.w, 16), tys = cdiv(a.h, 16);
-        conv3x3_kernel<NCO, 2, 1><<<dim3((unsigned)(ngroups * txs * tys), (unsigned)a.B), 256, 0, st>>>(a, ngroups, txs, vec);
-    }
+    // tile shape from the image width: 64x4, 32x8 or 16x16 pixels.  Workgroups are persistent over
+    // tiles of one (image, output group): as many workgroups as stay resident at once
+    // (LDS and registers: 2 per CU at NCO >= 3, 3 at NCO = 2, 4 at NCO = 1), each with the same number of tiles.
+    const int lrw = a.w > 32 ? 0 : (a.w > 16 ? 1 : 2);
+    // few output channels (NCO <= 2): every wave takes two pixel rows (8x64 tile), like NCO = 4 in MFMAs per barrier
+    constexpr int RPW2 = NCO <= 2 ? 2 : 1;
+    const int rpw = (lrw == 0 && a.h >= 8) ? RPW2 : 1;
+    const int txs = cdiv(a.w, 64 >> lrw), tys = cdiv(a.h, (4 << lrw) * rpw);
+    const int ntiles = txs * tys;
+    const long slots = 256L * (rpw == 2 || NCO >= 3 ? 2 : (NCO == 2 ? 3 : 4));
+    const long total = (long)ntiles * ngroups * a.B;
+    const int per_wg = (int)((total + slots - 1) / slots);
+    const int wgs = cdiv(ntiles, per_wg);
+    const dim3 grid((unsigned)(ngroups * wgs), (unsigned)a.B);
+    if (lrw == 0 && rpw == 2)
+        conv3x3_kernel<NCO, 0, RPW2><<<grid, 256, 0, st>>>(a, ngroups, txs, ntiles, vec);
+    else if (lrw == 0)
+        conv3x3_kernel<NCO, 0, 1><<<grid, 256, 0, st>>>(a, ngroups, txs, ntiles, vec);
+    else if (lrw == 1)
+        conv3x3_kernel<NCO, 1, 1><<<grid, 256, 0, st>>>(a, ngroups, txs, ntiles, vec);
+    else
+        conv3x3_kernel<NCO, 2, 1><<<grid, 256, 0, st>>>(a, ngroups, txs, ntiles, vec);
 }
 
 int launch_conv3x3(const Conv3x3Args& a, hipStream_t st) {
@@ -268,7 +332,7 @@ int launch_conv3x3(const Conv3x3Args& a, hipStream_t st) {
     const int ngroups = cdiv(NT, nco);
     const int vec = (a.w % 4 == 0) && aligned16(a.out) && (a.out_bstride % 4 == 0);
     char key[64];
-    snprintf(key, sizeof(key), "conv3x3_kernel<%d, %d, 1>", nco, a.w > 32 ? 0 : (a.w > 16 ? 1 : 2));
+    snprintf(key, sizeof(key), "conv3x3_kernel<%d, %d, %d>", nco, a.w > 32 ? 0 : (a.w > 16 ? 1 : 2), (nco <= 2 && a.w > 32 && a.h >= 8) ? 2 : 1);
     const double px = (double)a.B * a.h * a.w;
     ProfScope prof(st, key, 18.0 * a.Cin * a.Cout * px, 4.0 * px * (a.Cin + a.Cout));
     switch (nco) {

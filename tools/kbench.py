@@ -83,6 +83,12 @@ def main():
         if "attn" in a.what:
             report(f"L{lvl} chan_attn C={C}           {h}x{h}", timed(lambda: ops.channel_attention(
                 x, r(3 * C, C, 1, 1), r(3 * C), r(3 * C, 1, 3, 3), r(3 * C), r(8, 1, 1), r(C, C, 1, 1), r(C), 8)))
+    if "c3probe" in a.what:   # conv3x3 at controlled (Cin, Cout, size, batch): separates chunk count from image size
+        for ci, co, sz, bb in ((32, 32, 512, 8), (64, 32, 512, 8), (32, 32, 256, 32), (32, 32, 1024, 2), (64, 32, 256, 8),
+                               (16, 32, 512, 8), (32, 64, 512, 8), (64, 64, 512, 4)):
+            xx = r(bb, ci, sz, sz)
+            report(f"c3 {ci}->{co} {sz}x{sz} B={bb}", timed(lambda: ops.conv3x3(xx, r(co, ci, 3, 3), r(co), act="lrelu")))
+            del xx
     if "dwt" in a.what:
         x = r(B, d, S, S)
         report("dwt_init", timed(lambda: ops.dwt_init(x)))
