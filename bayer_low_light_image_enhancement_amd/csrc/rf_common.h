@@ -32,6 +32,18 @@ struct ProfScope {
     int rec_;
 };
 
+// GELU(v) = v/2 (1 + erf(v/sqrt 2)) with erf by Abramowitz-Stegun 7.1.26 (|error| <= 1.5e-7): one v_exp, one v_rcp, 6 fma
+__device__ __forceinline__ float gelu_fast(float v) {
+    const float x = fabsf(v) * 0.70710678118654752440f;
+    const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, x, 1.0f));
+    float p = fmaf(1.061405429f, t, -1.453152027f);
+    p = fmaf(p, t, 1.421413741f);
+    p = fmaf(p, t, -0.284496736f);
+    p = fmaf(p, t, 0.254829592f);
+    const float e = 1.0f - p * t * __expf(-x * x);       // erf(|v| / sqrt 2)
+    return 0.5f * v * (1.0f + copysignf(e, v));
+}
+
 static inline int cdiv(int a, int b) { return (a + b - 1) / b; }
 static inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 static inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }

@@ -54,18 +54,6 @@ constexpr int GPW = NG / 4;             // 27 groups per wave in phase A (two MF
 constexpr int PART = 32;                // intermediate channels per part
 }  // namespace fused
 
-// erf by Abramowitz-Stegun 7.1.26 (|error| <= 1.5e-7): one v_exp, one v_rcp, 6 fma
-__device__ __forceinline__ float gelu_fast(float v) {
-    const float x = fabsf(v) * 0.70710678118654752440f;
-    const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, x, 1.0f));
-    float p = fmaf(1.061405429f, t, -1.453152027f);
-    p = fmaf(p, t, 1.421413741f);
-    p = fmaf(p, t, -0.284496736f);
-    p = fmaf(p, t, 0.254829592f);
-    const float e = 1.0f - p * t * __expf(-x * x);       // erf(|v| / sqrt 2)
-    return 0.5f * v * (1.0f + copysignf(e, v));
-}
-
 // ---- shared phase-A machinery ------------------------------------------------------------------
 // The wave's two steps of halo'd pixel groups: geometry of step st for lane j.
 struct GroupGeom {

@@ -281,10 +281,13 @@ __global__ void __launch_bounds__(256, (KS <= 8 ? 3 : 2)) conv1x1_res_kernel(Con
 // ---------------------------------------------------------------------------------------------
 // Streaming kernel: accumulators for NCO tiles resident, K in chunks of KCH k-sets.
 // ---------------------------------------------------------------------------------------------
+static constexpr int kStreamLnMaxK = 1024;   // LayerNorm gamma/beta staged in LDS (RawFormer-L level 3 has K = 512)
+
 template <int NCO, int KCH, bool LN>
 __global__ void __launch_bounds__(256, 2) conv1x1_stream_kernel(Conv1x1Args a, int ngroups) {
     __shared__ __attribute__((aligned(16))) float lds_w[2][KCH * NCO * 64];
     __shared__ float bias_l[NCO * 16];
+    __shared__ float gam_l[LN ? kStreamLnMaxK : 4], bet_l[LN ? kStreamLnMaxK : 4];
     constexpr int WPT = KCH * NCO * 16 / 256;   // float4 of weights each thread moves per chunk
     static_assert(KCH * NCO * 16 % 256 == 0, "weight chunk must split evenly over the workgroup");
     const int tid = threadIdx.x;
@@ -305,6 +308,34 @@ __global__ void __launch_bounds__(256, 2) conv1x1_stream_kernel(Conv1x1Args a, i
     const unsigned voff = (unsigned)kq * (unsigned)P + (unsigned)(live ? p0 : 0);
     const float* wp = a.wp + (size_t)b * a.wp_bstride;
     stage_bias(a, bias_l, t0, NCO, tid);
+    if constexpr (LN) {
+        for (int i = tid; i < 4 * nch * KCH; i += 256) {          // zero beyond K: those k-sets meet zero weights anyway
+            gam_l[i] = i < K ? a.ln_w[i] : 0.f;
+            bet_l[i] = (a.ln_b && i < K) ? a.ln_b[i] : 0.f;
+        }
+    }
+
+    // The residual initialises the accumulators: its loads travel with the first chunk's (one exposed
+    // round trip instead of two) and the epilogue stays store-only.
+    f32x4 acc[NCO][4];
+#pragma unroll
+    for (int t = 0; t < NCO; ++t)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) acc[t][g] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    if (a.res && a.mode == 0 && live) {
+        const float* resb = a.res + (size_t)b * a.res_bstride;
+        const unsigned vo = (unsigned)(4 * kq) * (unsigned)P + (unsigned)p0;
+#pragma unroll
+        for (int t = 0; t < NCO; ++t)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int cu = 16 * (t0 + t) + r;
+                if (t < tcnt && cu + 4 * kq < a.Cout) {
+                    const float4 rv = ldv(resb + (size_t)cu * P, vo);
+                    acc[t][0][r] = rv.x; acc[t][1][r] = rv.y; acc[t][2][r] = rv.z; acc[t][3][r] = rv.w;
+                }
+            }
+    }
 
     // LayerNorm statistics (shifted single pass; lanes kq = 0..3 split the channels)
     float lnA[4] = {1.f, 1.f, 1.f, 1.f}, lnB[4] = {0.f, 0.f, 0.f, 0.f};
@@ -312,7 +343,7 @@ __global__ void __launch_bounds__(256, 2) conv1x1_stream_kernel(Conv1x1Args a, i
         const float4 s4 = ldv(kset_base(a, b, 0), (unsigned)(live ? p0 : 0));
         const float sh[4] = {s4.x, s4.y, s4.z, s4.w};
         float s1[4] = {0.f, 0.f, 0.f, 0.f}, s2[4] = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll 8
+#pragma unroll 16
         for (int s = 0; s < NS; ++s) {
             const float4 t = ldv(kset_base(a, b, s), voff);
             const float d[4] = {t.x - sh[0], t.y - sh[1], t.z - sh[2], t.w - sh[3]};
@@ -332,13 +363,7 @@ __global__ void __launch_bounds__(256, 2) conv1x1_stream_kernel(Conv1x1Args a, i
         }
     }
 
-    f32x4 acc[NCO][4];
-#pragma unroll
-    for (int t = 0; t < NCO; ++t)
-#pragma unroll
-        for (int g = 0; g < 4; ++g) acc[t][g] = (f32x4){0.f, 0.f, 0.f, 0.f};
-
-    float4 xc[KCH], xn[KCH], wr[WPT];
+    float4 xa[KCH], xb_[KCH], wr[WPT];
     auto load_x_chunk = [&](int c, float4 (&dst)[KCH]) {
 #pragma unroll
         for (int i = 0; i < KCH; ++i) {
@@ -360,12 +385,8 @@ __global__ void __launch_bounds__(256, 2) conv1x1_stream_kernel(Conv1x1Args a, i
 #pragma unroll
         for (int i = 0; i < WPT; ++i) *reinterpret_cast<float4*>(&lds_w[buf][(tid + 256 * i) * 4]) = wr[i];
     };
-
-    load_x_chunk(0, xc);
-    load_w_chunk(0);
-    store_w_chunk(0);
-    __syncthreads();
-    for (int c = 0; c < nch; ++c) {
+    // one chunk: the next chunk's x goes into the OTHER register set (no copies), its weights into the other LDS buffer
+    auto chunk = [&](int c, float4 (&xc)[KCH], float4 (&xn)[KCH]) {
         if (c + 1 < nch) {   // next chunk in flight while this one computes
             load_x_chunk(c + 1, xn);
             load_w_chunk(c + 1);
@@ -373,42 +394,32 @@ __global__ void __launch_bounds__(256, 2) conv1x1_stream_kernel(Conv1x1Args a, i
         const float* wl = &lds_w[c & 1][lane];
 #pragma unroll
         for (int i = 0; i < KCH; ++i) {
-            float xb[4] = {xc[i].x, xc[i].y, xc[i].z, xc[i].w};
+            float xv[4] = {xc[i].x, xc[i].y, xc[i].z, xc[i].w};
             if constexpr (LN) {
                 const int k = 4 * (c * KCH + i) + kq;
-                const float gk = k < K ? a.ln_w[k] : 0.f, bk = (a.ln_b && k < K) ? a.ln_b[k] : 0.f;
+                const float gk = gam_l[k], bk = bet_l[k];
 #pragma unroll
-                for (int g = 0; g < 4; ++g) xb[g] = fmaf(fmaf(xb[g], lnA[g], lnB[g]), gk, bk);
+                for (int g = 0; g < 4; ++g) xv[g] = fmaf(fmaf(xv[g], lnA[g], lnB[g]), gk, bk);
             }
 #pragma unroll
             for (int t = 0; t < NCO; ++t) {
                 const float av = wl[(i * NCO + t) * 64];
 #pragma unroll
                 for (int g = 0; g < 4; ++g)
-                    acc[t][g] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, xb[g], acc[t][g], 0, 0, 0);
+                    acc[t][g] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, xv[g], acc[t][g], 0, 0, 0);
             }
         }
-        if (c + 1 < nch) {
-            store_w_chunk((c + 1) & 1);
-#pragma unroll
-            for (int i = 0; i < KCH; ++i) xc[i] = xn[i];
-        }
+        if (c + 1 < nch) store_w_chunk((c + 1) & 1);
         __syncthreads();
-    }
-    // the residual is read here, after the k-loop: this kernel's stores are its last instructions
-    if (a.res && a.mode == 0 && live) {
-        const float* resb = a.res + (size_t)b * a.res_bstride;
-        const unsigned vo = (unsigned)(4 * kq) * (unsigned)P + (unsigned)p0;
-#pragma unroll
-        for (int t = 0; t < NCO; ++t)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int cu = 16 * (t0 + t) + r;
-                if (t < tcnt && cu + 4 * kq < a.Cout) {
-                    const float4 rv = ldv(resb + (size_t)cu * P, vo);
-                    acc[t][0][r] += rv.x; acc[t][1][r] += rv.y; acc[t][2][r] += rv.z; acc[t][3][r] += rv.w;
-                }
-            }
+    };
+
+    load_x_chunk(0, xa);
+    load_w_chunk(0);
+    store_w_chunk(0);
+    __syncthreads();
+    for (int c = 0; c < nch; c += 2) {
+        chunk(c, xa, xb_);
+        if (c + 1 < nch) chunk(c + 1, xb_, xa);
     }
     epilogue<NCO, false>(a, acc, t0, tcnt, bias_l, nullptr, b, p0, kq, live);
 }
@@ -494,7 +505,7 @@ int launch_conv1x1(const Conv1x1Args& a, hipStream_t st) {
     const double px = (double)a.B * a.P;
     const double work_flops = 2.0 * K * a.Cout * px, work_bytes = 4.0 * px * (K + a.Cout + (a.res ? a.Cout : 0));
     char key[64];
-    if (!vec || (a.res && a.Cout % 16 != 0)) {
+    if (!vec || (a.res && a.Cout % 16 != 0) || (a.ln_w && K > kStreamLnMaxK)) {
         ProfScope prof(st, "conv1x1_scalar_kernel", work_flops, work_bytes);
         int gx = cdiv(a.P, 256);
         if (gx > 4096) gx = 4096;

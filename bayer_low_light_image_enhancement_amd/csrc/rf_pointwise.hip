@@ -2,6 +2,7 @@
 // synthesis, per-pixel LayerNorm, depthwise 3x3.  One lane owns 4 consecutive pixels of a row
 // (16-byte accesses, 1 KiB per wave instruction) whenever the row length allows; a scalar
 // path covers ragged widths (e.g. w = 266 at level 3 of a 1424x2128 frame).
+#include <cstdlib>
 #include "rf_common.h"
 
 namespace rf {
@@ -321,7 +322,6 @@ int launch_layernorm2d(const float* in, float* out, const float* w, const float*
 // fetched from HBM once and re-served from L1 for the neighbouring strips.
 // Algorithmic bytes: 8 per element.
 // ------------------------------------------------------------------------------------------
-__device__ __forceinline__ float gelu_erf(float v) { return 0.5f * v * (1.0f + erff(v * 0.70710678118654752440f)); }
 
 template <int VEC, int ROWS>
 __global__ void __launch_bounds__(kBlock) dwconv3x3_kernel(DwConvArgs a) {
@@ -392,7 +392,7 @@ __global__ void __launch_bounds__(kBlock) dwconv3x3_kernel(DwConvArgs a) {
             if (y < h) {
                 if (a.gelu) {
 #pragma unroll
-                    for (int p = 0; p < VEC; ++p) acc[r][p] = gelu_erf(acc[r][p]);
+                    for (int p = 0; p < VEC; ++p) acc[r][p] = gelu_fast(acc[r][p]);
                 }
                 if constexpr (VEC == 4)
                     *reinterpret_cast<float4*>(o + (size_t)y * w + x0) = make_float4(acc[r][0], acc[r][1], acc[r][2], acc[r][3]);
@@ -406,8 +406,12 @@ __global__ void __launch_bounds__(kBlock) dwconv3x3_kernel(DwConvArgs a) {
 int launch_dwconv3x3(const DwConvArgs& a, hipStream_t st) {
     const bool vec = (a.w_ & 3) == 0 && aligned16(a.x) && aligned16(a.out) && (a.x_bstride & 3) == 0 && (a.out_bstride & 3) == 0;
     const double el = (double)a.B * a.C * a.h * a.w_;
-    ProfScope prof(st, vec ? "dwconv3x3_kernel<4, 4>" : "dwconv3x3_kernel<1, 4>", 18.0 * el, 8.0 * el);
-    if (vec) {
+    const bool tall = vec && a.h % 8 == 0 && getenv("RF_DW_ROWS4") == nullptr;   // 8 output rows per thread: 10 row loads per 8 rows instead of 6 per 4
+    ProfScope prof(st, vec ? (tall ? "dwconv3x3_kernel<4, 8>" : "dwconv3x3_kernel<4, 4>") : "dwconv3x3_kernel<1, 4>", 18.0 * el, 8.0 * el);
+    if (tall) {
+        const size_t items = (size_t)a.B * a.C * (a.h / 8) * (a.w_ / 4);
+        dwconv3x3_kernel<4, 8><<<grid_for(items), kBlock, 0, st>>>(a);
+    } else if (vec) {
         const size_t items = (size_t)a.B * a.C * cdiv(a.h, 4) * (a.w_ / 4);
         dwconv3x3_kernel<4, 4><<<grid_for(items), kBlock, 0, st>>>(a);
     } else {
