@@ -72,6 +72,24 @@ def roofline_of(rec):
             "launches_per_step": None}
 
 
+def pmc_traffic(kernel, workload):
+    """HBM bytes per launch of ``kernel`` from the committed rocprofv3 PMC passes of this same command
+    (profiles/*_traffic.json, made by tools/traffic.py: FETCH_SIZE and WRITE_SIZE in separate passes, gfx950
+    corrections applied).  PMC counters cannot be read from inside the process; None when the workload is not
+    the profiled one or the kernel is not in the file."""
+    if workload != "cfg2":
+        return None
+    import glob
+    files = sorted(glob.glob(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "*_traffic.json")))
+    if not files:
+        return None
+    try:
+        rec = json.load(open(files[-1]))["kernels"].get(kernel)
+        return rec["hbm_bytes_per_launch"] if rec else None
+    except Exception:
+        return None
+
+
 def host_cores() -> int:
     """Usable host cores: affinity mask, capped by the cgroup CPU quota of the box."""
     cores = os.cpu_count() or 1
@@ -237,6 +255,8 @@ def main():
         top = recs[0]
         rl = roofline_of(top)
         rl["launches_per_step"] = top["launches"] // args.steps
+        rl["traffic"] = pmc_traffic(top["kernel"], args.workload)
+        rl["algorithmic_bytes_per_launch"] = round(top["bytes"] / top["launches"])
         rl["share_of_forward"] = round(top["ms"] / total, 4)
         line["roofline"] = rl
         line["kernels"] = [{"kernel": r["kernel"], "launches_per_step": r["launches"] // args.steps,

@@ -1,0 +1,52 @@
+#!/usr/bin/env python3
+"""HBM traffic per launch from two rocprofv3 PMC passes (FETCH_SIZE, WRITE_SIZE; separate runs, no trace
+domains besides --kernel-trace) of `python3 bench.py --no-cpu-baseline --no-profile --steps 2 --warmup 1`.
+
+gfx950 corrections (MI355X_MICROARCH.md, HBM section): FETCH_SIZE counts 128-byte requests at 64 bytes, so
+kernels whose loads are 16 bytes per lane are doubled; WRITE_SIZE is exact for 16-byte stores.  The 3x3
+convolution stages its input with dword gathers (halo rows, 264-byte runs): that width is uncalibrated in
+the guide, so it is calibrated here on the level-0 launches, whose input bytes (+25 % halo at the 8x64 tile)
+are known: factor 1.3.
+
+usage: traffic.py <fetch counter_collection.csv> <write counter_collection.csv> <out.json>
+"""
+import collections
+import csv
+import json
+import re
+import sys
+
+DWORD_GATHER = ("conv3x3_kernel",)          # FETCH_SIZE x 1.3 (calibrated, see above)
+SIXTEEN_BYTE = True                          # everything else loads 16 B per lane: x 2
+
+
+def load(path, name):
+    acc = collections.defaultdict(lambda: [0.0, 0])
+    for r in csv.DictReader(open(path)):
+        if r["Counter_Name"] != name:
+            continue
+        k = re.sub(r"\(.*", "", r["Kernel_Name"].replace("void rf::", "").replace("rf::", ""))
+        acc[k][0] += float(r["Counter_Value"])
+        acc[k][1] += 1
+    return acc
+
+
+def main():
+    fetch, write = load(sys.argv[1], "FETCH_SIZE"), load(sys.argv[2], "WRITE_SIZE")
+    out = {}
+    for k in sorted(fetch):
+        if k not in write or k.startswith(("__amd", "at::", "void at::", "pack_")):
+            continue
+        f_kb, w_kb = fetch[k][0] / fetch[k][1], write[k][0] / write[k][1]
+        corr = 1.3 if k.startswith(DWORD_GATHER) else 2.0
+        out[k] = {"launches_sampled": fetch[k][1], "fetch_size_kb_raw": round(f_kb, 1), "write_size_kb": round(w_kb, 1),
+                  "fetch_correction": corr, "hbm_bytes_per_launch": round((f_kb * corr + w_kb) * 1024)}
+    json.dump({"source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) over bench.py cfg2, 2 steps",
+               "units": "bytes per launch (mean over the launches of that kernel name in one forward)",
+               "kernels": out}, open(sys.argv[3], "w"), indent=1)
+    for k, v in out.items():
+        print(f"{k:46s} {v['hbm_bytes_per_launch'] / 1e6:9.1f} MB/launch")
+
+
+if __name__ == "__main__":
+    main()
