@@ -65,6 +65,7 @@ SIGNATURES = {
     "rf_to_uint8_hwc": (_i, [_vp, _vp, _i, _i, _i, _i, _vp]),
     "rf_u8_sse": (_i, [_vp, _vp, _vp, _i, _sz, _vp]),
     "rf_u8_channel_sums": (_i, [_vp, _vp, _i, _i, _sz, _vp]),
+    "rf_sid_pack": (_i, [_vp, _vp, _i, _i, _i, _i, _i, C.c_double, _i, _vp]),
 }
 
 _lib = None

@@ -114,3 +114,32 @@ def evaluate(pred: torch.Tensor, gt: torch.Tensor, bayer_pattern: str = "RGGB", 
     psnr = psnr_u8(p8, g8)
     ssim = np.array([ssim_u8(p8[i].cpu().numpy(), g8[i].cpu().numpy()) for i in range(p8.shape[0])]) if with_ssim else np.array([])
     return psnr, ssim
+
+
+_SID_MODES = {"loader": 0, "rgbg": 0, "rggb": 1, "unshuffle": 1, "mosaic": 2}
+
+
+def pack_raw(raw: torch.Tensor, black_level: int, white_level: int, ratio: float = 1.0, layout: str = "loader") -> torch.Tensor:
+    """SID front-end on the device (correctdataloader.py:58-72 ``pack_raw``, :86 ``* ratio``, :103 ``min(., 1)``).
+
+    ``raw``: uint16 (or int16-viewed) Bayer frames ``[B, 2h, 2w]`` on the GPU; ``black_level`` =
+    ``min(raw.black_level_per_channel)``.  ``layout``: ``"loader"`` = the reference loader's channel order
+    (sites (0,0) (0,1) (1,1) (1,0)), ``"rggb"`` = ``pixel_unshuffle`` order, ``"mosaic"`` = normalised
+    ``[B,1,2h,2w]`` mosaic (the input of ``RawFormer.forward``)."""
+    if not raw.is_cuda:
+        raise RuntimeError("pack_raw: the SID front-end runs on the ROCm device only (no CPU fallback)")
+    if raw.dtype not in (torch.uint16, torch.int16):
+        raise TypeError(f"pack_raw: expected a uint16 Bayer frame, got {raw.dtype}")
+    if raw.dim() == 2:
+        raw = raw.unsqueeze(0)
+    raw = raw.contiguous()
+    B, H2, W2 = raw.shape
+    if H2 % 2 or W2 % 8:
+        raise ValueError(f"pack_raw: mosaic {H2}x{W2} must have an even height and a width that is a multiple of 8")
+    mode = _SID_MODES[layout]
+    h, w = H2 // 2, W2 // 2
+    out = torch.empty((B, 1, H2, W2) if mode == 2 else (B, 4, h, w), dtype=torch.float32, device=raw.device)
+    with torch.cuda.device(raw.device):
+        _lib.check(_lib.load().rf_sid_pack(C.c_void_p(raw.data_ptr()), C.c_void_p(out.data_ptr()), B, h, w, int(black_level),
+                                           int(white_level), float(ratio), mode, _stream(raw)), "rf_sid_pack")
+    return out

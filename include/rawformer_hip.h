@@ -159,6 +159,14 @@ int rf_u8_sse(const unsigned char* a, const unsigned char* b, unsigned long long
 /* per-image, per-channel sums of HWC uint8 images (auto_correct_rb compares channel means, test.py:31-40) */
 int rf_u8_channel_sums(const unsigned char* a, unsigned long long* sums, int B, int C, size_t hw, void* stream);
 
+/* ---- SID front-end: correctdataloader.py:58-72 (pack_raw), :86 (x ratio),
+ * :103 (min 1) fused into one pass over the uint16 Bayer frame [B, 2h, 2w]:
+ *   v = min(clip((raw - black) / (white - black), 0, 1) * ratio, 1), evaluated in double, rounded once.
+ * mode 0: the loader's packing [B,4,h,w] = sites (0,0) (0,1) (1,1) (1,0); mode 1: pixel_unshuffle order
+ * (0,0) (0,1) (1,0) (1,1) (a1); mode 2: normalised mosaic [B,1,2h,2w] (RawFormer.forward's input).
+ * black = min(black_level_per_channel); w % 4 == 0. */
+int rf_sid_pack(const unsigned short* raw, float* out, int B, int h, int w, int black, int white, double ratio, int mode, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

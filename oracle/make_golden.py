@@ -327,6 +327,29 @@ def harness():
         dark_red = u8.copy()
         dark_red[..., 0] //= 4
         out[f"auto_darkred_{i}"] = np.ascontiguousarray(ns["auto_correct_rb"](dark_red))
+    # SID packing (correctdataloader.py:58-72 pack_raw; :86 * ratio; :103 np.minimum(., 1); :136 .float()):
+    # the method's source text is executed against a stand-in for the rawpy object (three attributes)
+    dl = open(os.path.join(REF, "correctdataloader.py")).read()
+    seg = dl[dl.index("    def pack_raw(self, raw):"):dl.index("    def __getitem__")]
+    import textwrap
+    ns2 = {"np": np}
+    exec(compile(textwrap.dedent(seg), "correctdataloader.py#pack_raw", "exec"), ns2)
+
+    class _Raw:
+        pass
+    for i, (h2, w2, ratio) in enumerate(((8, 16, 100.0), (12, 24, 300.0), (16, 32, 28.5714285714))):
+        raw = _Raw()
+        raw.black_level_per_channel = [512, 512, 511, 512]
+        raw.white_level = 16383
+        u = synth.uniform(77 + i, "harness.raw", (h2, w2), 0.0, 1.0)
+        raw.raw_image_visible = (400 + u * u * 3000 + (u > 0.97) * 14000).astype(np.uint16)     # dark frame + a few saturated sites
+        packed = ns2["pack_raw"](None, raw) * ratio                        # :86
+        packed = np.minimum(packed, 1.0).transpose(2, 0, 1)                # :103, :106
+        out[f"sid_raw{i}"] = raw.raw_image_visible
+        out[f"sid_ratio{i}"] = np.float64(ratio)
+        out[f"sid_packed{i}"] = np.ascontiguousarray(packed).astype(np.float32)   # :136 .float()
+    out["sid_black"] = np.array([512, 512, 511, 512])
+    out["sid_white"] = np.int64(16383)
     save("harness", **out)
 
 
