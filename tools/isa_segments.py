@@ -1,12 +1,13 @@
 #!/usr/bin/env python3
 """Instruction-class counts per basic block of one kernel in a hipcc -S listing.
 usage: isa_segments.py <file.s> <mangled-name-substring> [min_mfma]"""
+import re
 import sys
 from collections import Counter
 src, name = sys.argv[1], sys.argv[2]
 minm = int(sys.argv[3]) if len(sys.argv) > 3 else 0
 lines = open(src).read().split("\n")
-start = next(i for i, l in enumerate(lines) if l.startswith("_Z") and name in l and l.rstrip().split(":")[0].endswith(("i", "E", "v")) or (l.startswith("_Z") and name in l and ":" in l))
+start = next(i for i, l in enumerate(lines) if l.startswith('_Z') and name in l.split(':')[0] and re.match(r'^_Z\w+:', l))
 seg, out = Counter(), []
 for i in range(start + 1, len(lines)):
     l = lines[i].strip()
