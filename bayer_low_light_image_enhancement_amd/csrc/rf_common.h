@@ -89,7 +89,7 @@ struct Conv1x1Args {
     int B, P;              // images, pixels per image
     int w;                 // image width (mode 1 only)
     int mode;              // 0: out[co][p]; 1: ConvTranspose2d 2x2 scatter, row co = 4*o + 2*i + j
-    int act;               // 0 none, 1 LeakyReLU(0.2)
+    int act;               // 0 none, 1 LeakyReLU(0.2), 2 ReLU
 };
 int launch_conv1x1(const Conv1x1Args& a, hipStream_t st);
 
@@ -102,7 +102,7 @@ struct Conv3x3Args {
     float* out;
     int64_t out_bstride;
     int B, Cin, Cout, h, w;
-    int act;               // 0 none, 1 LeakyReLU(0.2)
+    int act;               // 0 none, 1 LeakyReLU(0.2), 2 ReLU
     int store;             // 0 plain, 1 pixel-unshuffle, 2 pixel-shuffle
     int unshuffle_in;      // read the input through the Bayer pack (a1)
     int clamp_in;          // clamp input to [0,1] while loading

@@ -229,6 +229,7 @@ __global__ void __launch_bounds__(256, 2) conv3x3_kernel(Conv3x3Args a, int ngro
             for (int g = 0; g < 4; ++g) {
                 float u = acc[rr][t][g][r] + bs;
                 if (a.act == 1) u = u > 0.f ? u : 0.2f * u;
+                else if (a.act == 2) u = fmaxf(u, 0.f);
                 if (a.clamp_out) u = fminf(fmaxf(u, 0.f), 1.f);
                 v[r][g] = u;
             }

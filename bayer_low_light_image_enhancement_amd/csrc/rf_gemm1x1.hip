@@ -72,6 +72,9 @@ __device__ __forceinline__ void epilogue(const Conv1x1Args& a, f32x4 (&acc)[NCO]
                 if (a.act == 1) {
 #pragma unroll
                     for (int g = 0; g < 4; ++g) v[g] = v[g] > 0.f ? v[g] : 0.2f * v[g];
+                } else if (a.act == 2) {
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) v[g] = fmaxf(v[g], 0.f);
                 }
                 if (live && cu + 4 * kq < a.Cout)
                     *reinterpret_cast<float4*>(outb + (size_t)cu * P + voff) = make_float4(v[0], v[1], v[2], v[3]);
@@ -458,6 +461,7 @@ __global__ void __launch_bounds__(256) conv1x1_scalar_kernel(Conv1x1Args a) {
                 s += a.bias ? a.bias[co] : 0.f;
                 if (a.res) s += a.res[(size_t)b * a.res_bstride + (size_t)co * P + p];
                 if (a.act == 1) s = s > 0.f ? s : 0.2f * s;
+                else if (a.act == 2) s = fmaxf(s, 0.f);
                 a.out[(size_t)b * a.out_bstride + (size_t)co * P + p] = s;
             } else {
                 const int o = co >> 2, y = p / a.w, x = p - y * a.w;

@@ -193,7 +193,7 @@ def dwconv3x3(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor
 
 def conv3x3(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor] = None, act: str = "none",
             store: str = "plain") -> torch.Tensor:
-    """``nn.Conv2d(Cin, Cout, 3, padding=1)``; ``act='lrelu'`` adds LeakyReLU(0.2);
+    """``nn.Conv2d(Cin, Cout, 3, padding=1)``; ``act='lrelu'`` adds LeakyReLU(0.2), ``'relu'`` ReLU;
     ``store='unshuffle'`` = Downsample (a8), ``'shuffle'`` = conv_out + PixelShuffle (a10)."""
     x, weight = _chk(x, "x"), _chk(weight, "weight")
     bias = None if bias is None else _chk(bias, "bias")
@@ -209,7 +209,7 @@ def conv3x3(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor] 
     scratch = _scratch(sz.value, x)
     out = torch.empty(shape, dtype=x.dtype, device=x.device)
     with torch.cuda.device(x.device):
-        _lib.check(lib.rf_conv3x3(_ptr(x), _ptr(out), _ptr(weight), _ptr(bias), _ptr(scratch), {"none": 0, "lrelu": 1}[act], mode,
+        _lib.check(lib.rf_conv3x3(_ptr(x), _ptr(out), _ptr(weight), _ptr(bias), _ptr(scratch), {"none": 0, "lrelu": 1, "relu": 2}[act], mode,
                                   b, cin, cout, h, w, _stream(x)), "rf_conv3x3")
     return out
 
@@ -316,3 +316,62 @@ def flca(feat: torch.Tensor, x4: torch.Tensor, params, prefix: str = "") -> torc
     with torch.cuda.device(feat.device):
         _lib.check(lib.rf_flca(_ptr(feat), _ptr(guide), _ptr(out), ptrs, _ptr(scratch), b, c, h, w, _stream(feat)), "rf_flca")
     return out
+
+
+def token_attention(qkv: torch.Tensor, heads: int, scale: Optional[float] = None) -> torch.Tensor:
+    """``softmax(q k^T * scale) v`` per (image, head) with tokens = pixels (Attenblock.py:212-217), flash style:
+    ``qkv`` is ``[B, 3*heads*d, H, W]`` (q, k, v thirds, channel = head*d + i), the result ``[B, heads*d, H, W]``."""
+    qkv = _chk(qkv, "qkv")
+    b, c3, h, w = qkv.shape
+    if c3 % (3 * heads):
+        raise RuntimeError(f"token_attention: {c3} channels are not 3 x {heads} heads x d")
+    inner = c3 // 3
+    d, n = inner // heads, h * w
+    out = torch.empty((b, inner, h, w), dtype=qkv.dtype, device=qkv.device)
+    q = qkv.data_ptr()
+    with torch.cuda.device(qkv.device):
+        _lib.check(_lib.load().rf_token_attn(C.c_void_p(q), C.c_void_p(q + 4 * inner * n), C.c_void_p(q + 8 * inner * n), _ptr(out),
+                                             3 * inner * n, inner * n, b, heads, d, n, float(d ** -0.5 if scale is None else scale),
+                                             _stream(qkv)), "rf_token_attn")
+    return out
+
+
+def luma_film(qkv: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, luma: Optional[torch.Tensor] = None,
+              alpha: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """FiLM ``gamma * t + beta`` on the q, k, v thirds of ``qkv`` and the query bias
+    ``alpha * centered(avg_pool3(1 - luma))`` (Attenblock.py:193-210)."""
+    qkv, gamma, beta = _chk(qkv, "qkv"), _chk(gamma, "gamma"), _chk(beta, "beta")
+    b, c3, h, w = qkv.shape
+    inner = c3 // 3
+    if tuple(gamma.shape) != (b, inner, h, w) or tuple(beta.shape) != (b, inner, h, w):
+        raise RuntimeError(f"luma_film: gamma/beta {tuple(gamma.shape)} do not match {(b, inner, h, w)}")
+    if luma is not None:
+        luma = _chk(luma, "luma")
+        if tuple(luma.shape) != (b, 1, h, w):
+            raise RuntimeError(f"luma_film: luma {tuple(luma.shape)} must be {(b, 1, h, w)}")
+        alpha = _chk(alpha, "alpha")
+    lib = _lib.load()
+    sz = C.c_size_t()
+    _lib.check(lib.rf_luma_film_scratch_bytes(b, h, w, C.byref(sz)), "rf_luma_film_scratch_bytes")
+    scratch = _scratch(sz.value, qkv)
+    out = torch.empty_like(qkv)
+    with torch.cuda.device(qkv.device):
+        _lib.check(lib.rf_luma_film(_ptr(qkv), _ptr(gamma), _ptr(beta), inner * h * w, _ptr(luma), _ptr(alpha), _ptr(out), _ptr(scratch),
+                                    b, inner, h, w, _stream(qkv)), "rf_luma_film")
+    return out
+
+
+def luminance_aware_mhsa(x: torch.Tensor, luma: torch.Tensor, params, heads: int = 8, prefix: str = "") -> torch.Tensor:
+    """``LuminanceAwareMHSA.forward(x, luma)`` (Attenblock.py:161-220) from its state_dict ``params``
+    (``to_qkv``, ``proj``, ``luma_cond.net.{0,2}``, ``luma_cond.{gamma,beta}``, ``alpha``): 1x1 GEMM, two 3x3
+    convs + ReLU, two 1x1 GEMMs, FiLM + luma bias, flash token attention, 1x1 GEMM."""
+    p = lambda k: params[prefix + k]  # noqa: E731
+    qkv = conv1x1(x, p("to_qkv.weight"), params.get(prefix + "to_qkv.bias"))
+    hcond = conv3x3(luma, p("luma_cond.net.0.weight"), p("luma_cond.net.0.bias"), act="relu")
+    hcond = conv3x3(hcond, p("luma_cond.net.2.weight"), p("luma_cond.net.2.bias"), act="relu")
+    gamma = conv1x1(hcond, p("luma_cond.gamma.weight"), p("luma_cond.gamma.bias"))
+    beta = conv1x1(hcond, p("luma_cond.beta.weight"), p("luma_cond.beta.bias"))
+    alpha = params.get(prefix + "alpha")
+    qkv = luma_film(qkv, gamma, beta, luma if alpha is not None else None, None if alpha is None else alpha.reshape(1))
+    out = token_attention(qkv, heads)
+    return conv1x1(out, p("proj.weight"), params.get(prefix + "proj.bias"))

@@ -113,7 +113,7 @@ int rf_conv1x1(const float* in, const float* in2, float* out, const float* weigh
 int rf_dwconv3x3(const float* in, float* out, const float* weight, const float* bias, int gelu,
                  int B, int C, int h, int w, void* stream);
 /* nn.Conv2d(Cin, Cout, 3, padding=1) with raw [Cout,Cin,3,3] weights.
- * act: 0 none, 1 LeakyReLU(0.2).  store: 0 plain, 1 pixel-unshuffle (Downsample,
+ * act: 0 none, 1 LeakyReLU(0.2), 2 ReLU (LumaCond, Attenblock.py:148-153).  store: 0 plain, 1 pixel-unshuffle (Downsample,
  * RawFomer_WFB_FFAB/model.py:300-307), 2 pixel-shuffle (conv_out + PixelShuffle, :505-507). */
 int rf_conv3x3_scratch_bytes(int Cin, int Cout, size_t* bytes);
 int rf_conv3x3(const float* in, float* out, const float* weight, const float* bias, void* scratch,
@@ -166,6 +166,19 @@ int rf_u8_channel_sums(const unsigned char* a, unsigned long long* sums, int B, 
  * (0,0) (0,1) (1,0) (1,1) (a1); mode 2: normalised mosaic [B,1,2h,2w] (RawFormer.forward's input).
  * black = min(black_level_per_channel); w % 4 == 0. */
 int rf_sid_pack(const unsigned short* raw, float* out, int B, int h, int w, int black, int white, double ratio, int mode, void* stream);
+
+/* ---- luminance-aware token attention: Attenblock.py:161-220 -----------------
+ * softmax(q_i . k_j * scale) v_j per (image, head), flash style (the N x N scores are never stored).
+ * q, k, v: [B, heads*d, N] with `bstride_qkv` floats between images (so they may be the three thirds of one
+ * [B, 3*heads*d, N] tensor); out: [B, heads*d, N].  Einsums of Attenblock.py:212-216.  d <= 32. */
+int rf_token_attn(const float* q, const float* k, const float* v, float* out, long long bstride_qkv, long long bstride_out,
+                  int B, int heads, int d, int N, float scale, void* stream);
+/* FiLM of q,k,v and the query luma bias (Attenblock.py:193-210): out = gamma * qkv + beta on each third of
+ * qkv [B, 3*inner, h*w]; the q third also gets alpha * (avg_pool3(1 - luma) - mean) when luma [B,1,h,w] != NULL.
+ * gamma, beta: [B, inner, h*w] with `gb_bstride` floats between images; alpha: device scalar. */
+int rf_luma_film_scratch_bytes(int B, int h, int w, size_t* bytes);
+int rf_luma_film(const float* qkv, const float* gamma, const float* beta, long long gb_bstride, const float* luma, const float* alpha,
+                 float* out, void* scratch, int B, int inner, int h, int w, void* stream);
 
 #ifdef __cplusplus
 }

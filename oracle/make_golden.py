@@ -353,6 +353,28 @@ def harness():
     save("harness", **out)
 
 
+ATTEN_CASES = (("d4", 32, 8, 2, 16, 16), ("d6", 48, 8, 1, 12, 20), ("d16", 64, 4, 1, 8, 24), ("d32", 64, 2, 1, 16, 16))
+
+
+def attenblock():
+    """a16: ``Attenblock.LuminanceAwareMHSA`` (imports cleanly: torch + einops) on seeded weights and inputs."""
+    sys.path.insert(0, REF)
+    import Attenblock as ab
+    out = {}
+    for tag, dim, heads, b, h, w in ATTEN_CASES:
+        m = fill(ab.LuminanceAwareMHSA(dim, heads=heads), 700 + dim + heads)
+        x = rnd(41, f"atten.{tag}.x", (b, dim, h, w))
+        luma = rnd(42, f"atten.{tag}.luma", (b, 1, h, w), 0.0, 1.0)
+        with torch.no_grad():
+            y = m(x, luma=luma)
+            mine = R.luminance_aware_mhsa(x, luma, sd_of(m), "", heads)
+        log(f"  LuminanceAwareMHSA {tag} dim={dim} heads={heads} {b}x{h}x{w}: oracle vs reference {maxabs(y, mine):.2e}  |y|max {float(y.abs().max()):.3f}")
+        assert maxabs(y, mine) < 2e-5
+        out[f"{tag}.out"] = y
+        out[f"{tag}.checksum_x"] = checksum(x)
+    save("attenblock", **out)
+
+
 def state_dict_keys(flca_mod):
     """Key names and shapes of the reference's state_dict (what test.py:88-91 loads strictly)."""
     import json
@@ -371,6 +393,7 @@ def main():
     ap.add_argument("--big", action="store_true", help="also run BASELINE configs 2-3 (minutes of CPU)")
     ap.add_argument("--only-keys", action="store_true", help="only (re)write state_dict_keys.json")
     ap.add_argument("--only-harness", action="store_true", help="only the evaluation-harness fixture (test.py helpers)")
+    ap.add_argument("--only-attenblock", action="store_true", help="only the Attenblock.LuminanceAwareMHSA fixture (a16)")
     ap.add_argument("--only-cfg4", action="store_true", help="only BASELINE config 4 (RawFormer-L, one 2848x4256 mosaic)")
     args = ap.parse_args()
     if args.only_keys:
@@ -380,6 +403,13 @@ def main():
     if args.only_harness:
         os.makedirs(GOLD, exist_ok=True)
         harness()
+        return
+    if args.only_attenblock:
+        os.makedirs(GOLD, exist_ok=True)
+        import_reference()
+        attenblock()
+        with open(os.path.join(GOLD, "PINNING.txt"), "a") as f:
+            f.write("\n".join(LOG) + "\n")
         return
     if args.only_cfg4:
         torch.set_num_threads(8)
@@ -391,6 +421,7 @@ def main():
     mods = import_reference()
     per_op(*mods)
     whole_model(mods[0], args.big)
+    attenblock()
     state_dict_keys(mods[0])
     with open(os.path.join(GOLD, "PINNING.txt"), "w") as f:
         f.write("# written by oracle/make_golden.py: reference (run on CPU here) vs oracle/rawformer_ref.py\n")

@@ -388,3 +388,39 @@ def param_shapes(cfg: RawFormerConfig, inp_channels: int = 1, out_channels: int 
     s["conv_out.weight"] = (out_channels * 4, d, 3, 3)
     s["conv_out.bias"] = (out_channels * 4,)
     return s
+
+
+# ------------------------------------------------------------------------------------------
+# a16: luminance-aware token attention (Attenblock.py:143-220).  Tokens are pixels; d = C / heads.
+# ------------------------------------------------------------------------------------------
+def token_attention(qkv: Tensor, heads: int) -> Tensor:
+    """Attenblock.py:190-191, 212-217: softmax(q k^T d^-1/2) v per head, [B,3*inner,h,w] -> [B,inner,h,w]."""
+    b, c3, h, w = qkv.shape
+    inner = c3 // 3
+    d = inner // heads
+    q, k, v = (t.reshape(b, heads, d, h * w).transpose(2, 3) for t in qkv.chunk(3, dim=1))     # b h N d
+    attn = torch.softmax(torch.matmul(q, k.transpose(2, 3)) * (d ** -0.5), dim=-1)
+    return torch.matmul(attn, v).transpose(2, 3).reshape(b, inner, h, w)
+
+
+def luma_film(qkv: Tensor, gamma: Tensor, beta: Tensor, luma: Optional[Tensor], alpha: Optional[Tensor]) -> Tensor:
+    """Attenblock.py:193-210: FiLM on q, k, v; centred, 3x3-average-pooled (1 - luma) scaled by alpha added to q."""
+    q, k, v = qkv.chunk(3, dim=1)
+    q, k, v = gamma * q + beta, gamma * k + beta, gamma * v + beta
+    if luma is not None:
+        inv = F.avg_pool2d(1.0 - luma, 3, padding=1, stride=1)
+        inv = inv - inv.mean(dim=(2, 3), keepdim=True)
+        q = q + alpha * inv
+    return torch.cat((q, k, v), dim=1)
+
+
+def luminance_aware_mhsa(x: Tensor, luma: Tensor, p: Dict[str, Tensor], pre: str, heads: int) -> Tensor:
+    """LuminanceAwareMHSA.forward(x, luma) (Attenblock.py:177-220) incl. LumaCond (143-159)."""
+    qkv = F.conv2d(x, p[pre + "to_qkv.weight"], p.get(pre + "to_qkv.bias"))
+    hc = F.relu(F.conv2d(luma, p[pre + "luma_cond.net.0.weight"], p[pre + "luma_cond.net.0.bias"], padding=1))
+    hc = F.relu(F.conv2d(hc, p[pre + "luma_cond.net.2.weight"], p[pre + "luma_cond.net.2.bias"], padding=1))
+    gamma = F.conv2d(hc, p[pre + "luma_cond.gamma.weight"], p[pre + "luma_cond.gamma.bias"])
+    beta = F.conv2d(hc, p[pre + "luma_cond.beta.weight"], p[pre + "luma_cond.beta.bias"])
+    alpha = p.get(pre + "alpha")
+    qkv = luma_film(qkv, gamma, beta, luma if alpha is not None else None, alpha)
+    return F.conv2d(token_attention(qkv, heads), p[pre + "proj.weight"], p.get(pre + "proj.bias"))

@@ -85,3 +85,24 @@ def model_state(dim, seed, variant="flca"):
     cfg = R.RawFormerConfig(dim=dim, variant=variant)
     shapes = R.param_shapes(cfg)
     return {k: torch.from_numpy(synth.param_values(seed, k, s)).reshape(s) for k, s in shapes.items()}
+
+
+# a16: Attenblock.LuminanceAwareMHSA cases of tests/golden/attenblock.npz: (tag, dim, heads, B, h, w)
+ATTEN_CASES = (("d4", 32, 8, 2, 16, 16), ("d6", 48, 8, 1, 12, 20), ("d16", 64, 4, 1, 8, 24), ("d32", 64, 2, 1, 16, 16))
+
+
+def atten_spec(dim, heads):
+    inner = heads * (dim // heads)
+    hid = max(16, inner // 2)
+    return {"alpha": (), "to_qkv.weight": (3 * inner, dim, 1, 1), "to_qkv.bias": (3 * inner,),
+            "proj.weight": (dim, inner, 1, 1), "proj.bias": (dim,),
+            "luma_cond.net.0.weight": (hid, 1, 3, 3), "luma_cond.net.0.bias": (hid,),
+            "luma_cond.net.2.weight": (hid, hid, 3, 3), "luma_cond.net.2.bias": (hid,),
+            "luma_cond.gamma.weight": (inner, hid, 1, 1), "luma_cond.gamma.bias": (inner,),
+            "luma_cond.beta.weight": (inner, hid, 1, 1), "luma_cond.beta.bias": (inner,)}
+
+
+def atten_inputs(tag, dim, heads, b, h, w):
+    x = rnd(f"atten.{tag}.x", (b, dim, h, w), seed=41)
+    luma = rnd(f"atten.{tag}.luma", (b, 1, h, w), 0.0, 1.0, seed=42)
+    return x, luma, params(atten_spec(dim, heads), seed=700 + dim + heads)

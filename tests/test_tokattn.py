@@ -1,0 +1,68 @@
+"""a16: luminance-aware token attention, Attenblock.py:143-220.
+CPU: the oracle against the reference's own outputs (tests/golden/attenblock.npz, written by
+oracle/make_golden.py --only-attenblock from ``Attenblock.LuminanceAwareMHSA``).  GPU: the HIP path
+(1x1 / 3x3 kernels, FiLM kernel, flash token-attention kernel) against both."""
+import numpy as np
+import pytest
+import torch
+
+import cases
+from cases import ATTEN_CASES, atten_inputs, golden
+from oracle import rawformer_ref as R
+
+TOL = 2e-5     # max-abs on O(1) outputs, as for the other operators
+
+
+def test_oracle_matches_reference_attenblock():
+    g = golden("attenblock")
+    for tag, dim, heads, b, h, w in ATTEN_CASES:
+        x, luma, p = atten_inputs(tag, dim, heads, b, h, w)
+        assert abs(float(x.double().sum()) - float(g[f"{tag}.checksum_x"])) < 1e-6
+        y = R.luminance_aware_mhsa(x, luma, p, "", heads)
+        assert float((y - torch.from_numpy(g[f"{tag}.out"])).abs().max()) < 1e-6
+
+
+@pytest.mark.gpu
+def test_luminance_aware_mhsa_matches_reference(device):
+    from bayer_low_light_image_enhancement_amd import ops
+    g = golden("attenblock")
+    for tag, dim, heads, b, h, w in ATTEN_CASES:
+        x, luma, p = atten_inputs(tag, dim, heads, b, h, w)
+        pd = {k: v.to(device) for k, v in p.items()}
+        y = ops.luminance_aware_mhsa(x.to(device), luma.to(device), pd, heads=heads).cpu()
+        assert float((y - torch.from_numpy(g[f"{tag}.out"])).abs().max()) < TOL, tag
+
+
+@pytest.mark.gpu
+def test_token_attention_peaked_and_ragged(device):
+    """Large logits (softmax far from uniform), N not a multiple of 16 or 64, every supported head size."""
+    from bayer_low_light_image_enhancement_amd import ops, synth
+    for heads, d, h, w in ((8, 4, 16, 16), (2, 6, 7, 9), (3, 12, 5, 13), (4, 16, 20, 12), (1, 32, 9, 31), (2, 20, 33, 8)):
+        qkv = torch.from_numpy(synth.uniform(5, f"tok.{heads}.{d}", (2, 3 * heads * d, h, w), -3.0, 3.0))
+        ref = R.token_attention(qkv.double(), heads).float()
+        got = ops.token_attention(qkv.to(device), heads).cpu()
+        assert float((got - ref).abs().max()) < TOL, (heads, d, h, w)
+    # a stage-sized case: N = 4096 tokens (scores would be 8 x 4096^2 floats = 537 MB per image un-tiled)
+    qkv = torch.from_numpy(synth.uniform(6, "tok.big", (1, 96, 64, 64), -2.0, 2.0))
+    got = ops.token_attention(qkv.to(device), 8).cpu()
+    ref = R.token_attention(qkv.double(), 8).float()
+    assert float((got - ref).abs().max()) < TOL
+    with pytest.raises(RuntimeError):
+        ops.token_attention(torch.zeros(1, 3 * 40, 4, 4, device=device), 1)     # d = 40 > 32
+
+
+@pytest.mark.gpu
+def test_luma_film_matches_oracle(device):
+    from bayer_low_light_image_enhancement_amd import ops, synth
+    b, inner, h, w = 2, 24, 9, 14
+    qkv = torch.from_numpy(synth.uniform(7, "film.qkv", (b, 3 * inner, h, w), -1, 1))
+    gam = torch.from_numpy(synth.uniform(7, "film.g", (b, inner, h, w), 0.5, 1.5))
+    bet = torch.from_numpy(synth.uniform(7, "film.b", (b, inner, h, w), -1, 1))
+    luma = torch.from_numpy(synth.uniform(7, "film.l", (b, 1, h, w), 0, 1))
+    alpha = torch.tensor(0.8)
+    ref = R.luma_film(qkv, gam, bet, luma, alpha)
+    got = ops.luma_film(qkv.to(device), gam.to(device), bet.to(device), luma.to(device), alpha.reshape(1).to(device)).cpu()
+    assert float((got - ref).abs().max()) < 2e-6
+    ref0 = R.luma_film(qkv, gam, bet, None, None)
+    got0 = ops.luma_film(qkv.to(device), gam.to(device), bet.to(device)).cpu()
+    assert torch.equal(got0, ref0)                     # one fma-free multiply-add per element: bit-exact
