@@ -69,6 +69,8 @@ SIGNATURES = {
     "rf_token_attn": (_i, [_vp, _vp, _vp, _vp, C.c_longlong, C.c_longlong, _i, _i, _i, _i, _f, _vp]),
     "rf_luma_film_scratch_bytes": (_i, [_i, _i, _i, _psz]),
     "rf_luma_film": (_i, [_vp, _vp, _vp, C.c_longlong, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
+    "rf_dwgate3x3": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
+    "rf_dwconv5x5": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
 }
 
 _lib = None

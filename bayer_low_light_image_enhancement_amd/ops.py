@@ -375,3 +375,67 @@ def luminance_aware_mhsa(x: torch.Tensor, luma: torch.Tensor, params, heads: int
     qkv = luma_film(qkv, gamma, beta, luma if alpha is not None else None, None if alpha is None else alpha.reshape(1))
     out = token_attention(qkv, heads)
     return conv1x1(out, p("proj.weight"), params.get(prefix + "proj.bias"))
+
+
+def dwgate3x3(x: torch.Tensor, wa: torch.Tensor, ba: Optional[torch.Tensor], wb: torch.Tensor, bb: Optional[torch.Tensor]) -> torch.Tensor:
+    """``gelu(g) * a + gelu(a) * g`` with ``a = dw3x3(x; wa, ba)``, ``g = dw3x3(x; wb, bb)`` in one pass
+    (middle of the WFB ``FeedForward``, RawFomer_WFB_FFAB/model.py:55-59 with the rep-conv branch fused)."""
+    x, wa, wb = _chk(x, "x"), _chk(wa, "wa"), _chk(wb, "wb")
+    b, c, h, w = x.shape
+    out = torch.empty_like(x)
+    with torch.cuda.device(x.device):
+        _lib.check(_lib.load().rf_dwgate3x3(_ptr(x), _ptr(out), _ptr(wa), _ptr(None if ba is None else _chk(ba, "ba")), _ptr(wb),
+                                            _ptr(None if bb is None else _chk(bb, "bb")), b, c, h, w, _stream(x)), "rf_dwgate3x3")
+    return out
+
+
+def dwconv5x5(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """``nn.Conv2d(C, C, 5, padding=2, groups=C)`` (Illumination_Estimator.depth_conv, model.py:182-183)."""
+    x, weight = _chk(x, "x"), _chk(weight, "weight")
+    b, c, h, w = x.shape
+    if tuple(weight.shape) != (c, 1, 5, 5):
+        raise RuntimeError(f"dwconv5x5: weight {tuple(weight.shape)} does not match {c} channels")
+    out = torch.empty_like(x)
+    with torch.cuda.device(x.device):
+        _lib.check(_lib.load().rf_dwconv5x5(_ptr(x), _ptr(out), _ptr(weight), _ptr(None if bias is None else _chk(bias, "bias")),
+                                            b, c, h, w, _stream(x)), "rf_dwconv5x5")
+    return out
+
+
+def fuse_rep_convs(params, prefix: str = "", eps: float = 1e-5):
+    """``FeedForward.fuse()`` (RawFomer_WFB_FFAB/model.py:27-40, 66-87) on a state_dict: the depthwise 3x3 + BN,
+    the depthwise 1x1 + BN and the identity as ONE depthwise 3x3 weight and bias (weight preparation, host side)."""
+    def bn_fold(name):
+        s = params[prefix + name + ".bn.weight"] / torch.sqrt(params[prefix + name + ".bn.running_var"] + eps)
+        wgt = params[prefix + name + ".c.weight"] * s[:, None, None, None]
+        return wgt, params[prefix + name + ".bn.bias"] - params[prefix + name + ".bn.running_mean"] * s
+    w1, b1 = bn_fold("rep_conv1")
+    w2, b2 = bn_fold("rep_conv2")
+    ident = torch.zeros_like(w1)
+    ident[:, :, 1, 1] = 1.0
+    return (w1 + torch.nn.functional.pad(w2, [1, 1, 1, 1]) + ident).contiguous(), (b1 + b2).contiguous()
+
+
+def wfb_feed_forward(x: torch.Tensor, params, prefix: str = "") -> torch.Tensor:
+    """Eval-mode ``FeedForward.forward`` (RawFomer_WFB_FFAB/model.py:42-62): 1x1, fused gate pass, 1x1 + identity."""
+    p = lambda k: params.get(prefix + k)  # noqa: E731
+    wa, ba = fuse_rep_convs(params, prefix)
+    hid = conv1x1(x, p("project_in.weight"), p("project_in.bias"))
+    gated = dwgate3x3(hid, wa, ba, p("dwconv.weight"), p("dwconv.bias"))
+    return conv1x1(gated, p("project_out.weight"), p("project_out.bias"), residual=x)
+
+
+def illumination_estimator(img: torch.Tensor, params, prefix: str = "") -> Tuple[torch.Tensor, torch.Tensor]:
+    """``Illumination_Estimator.forward`` (RawFomer_WFB_FFAB/model.py:186-200) -> (illu_fea, illu_map).  The channel
+    mean that the reference concatenates folds into conv1's weights: W [img ; mean] = (W_img + w_mean / C) img."""
+    img = _chk(img, "img")
+    b, c, h, w = img.shape
+    w1 = params[prefix + "conv1.weight"]
+    if w1.shape[1] != c + 1:
+        raise RuntimeError(f"illumination_estimator: conv1 expects {w1.shape[1]} = C + 1 channels, image has {c}")
+    pad = (-c) % 4                                        # the GEMM kernels take channel counts in multiples of 4
+    wf = torch.cat([w1[:, :c] + w1[:, c:] / c, w1.new_zeros(w1.shape[0], pad, 1, 1)], dim=1).contiguous()
+    xin = torch.cat([img, img.new_zeros(b, pad, h, w)], dim=1) if pad else img
+    x1 = conv1x1(xin, wf, params.get(prefix + "conv1.bias"))
+    fea = dwconv5x5(x1, params[prefix + "depth_conv.weight"], params.get(prefix + "depth_conv.bias"))
+    return fea, conv1x1(fea, params[prefix + "conv2.weight"], params.get(prefix + "conv2.bias"))

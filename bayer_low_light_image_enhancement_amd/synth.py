@@ -64,6 +64,8 @@ def param_values(seed: int, name: str, shape) -> np.ndarray:
         raise ValueError(f"{name} is a fixed buffer, not a generated parameter")
     if leaf in ("alpha", "beta", "gamma"):
         return uniform(seed, name, shape, 0.5, 1.5)
+    if leaf == "running_var":  # BatchNorm statistics must stay positive
+        return uniform(seed, name, shape, 0.5, 1.5)
     if leaf in ("temperature", "scale", "log_temperature"):
         return uniform(seed, name, shape, 0.5, 2.0)
     if len(shape) == 1:

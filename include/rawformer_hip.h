@@ -180,6 +180,14 @@ int rf_luma_film_scratch_bytes(int B, int h, int w, size_t* bytes);
 int rf_luma_film(const float* qkv, const float* gamma, const float* beta, long long gb_bstride, const float* luma, const float* alpha,
                  float* out, void* scratch, int B, int inner, int h, int w, void* stream);
 
+/* ---- WFB extras without Mamba: RawFomer_WFB_FFAB/model.py:42-87, 174-200 -------
+ * Middle of the gated FeedForward in eval mode: a = dw3x3(x; wa, ba) (the fused rep-conv branch, fuse() at
+ * model.py:66-87), g = dw3x3(x; wb, bb) (dwconv), out = gelu(g) * a + gelu(a) * g (model.py:59); one pass. */
+int rf_dwgate3x3(const float* in, float* out, const float* wa, const float* ba, const float* wb, const float* bb,
+                 int B, int C, int h, int w, void* stream);
+/* nn.Conv2d(C, C, 5, padding=2, groups=C) (+bias): Illumination_Estimator.depth_conv (model.py:182-183) */
+int rf_dwconv5x5(const float* in, float* out, const float* weight, const float* bias, int B, int C, int h, int w, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

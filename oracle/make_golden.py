@@ -375,6 +375,41 @@ def attenblock():
     save("attenblock", **out)
 
 
+WFB_FF_CASES = (("ff32", 32, 2.0, 2, 16, 24), ("ff48", 48, 2.5, 1, 10, 14))
+WFB_IE_CASES = (("ie32", 32, 2, 16, 24), ("ie40", 40, 1, 9, 14))
+
+
+def wfb_extras():
+    """a17: ``FeedForward`` (+``Conv2d_BN``) and ``Illumination_Estimator`` of RawFomer_WFB_FFAB/model.py.  The module
+    itself needs mamba_ssm at import, so only these class definitions (model.py:17-87, 174-200; torch only) are
+    executed from the source text."""
+    src = open(os.path.join(REF, "RawFomer_WFB_FFAB", "model.py")).read()
+    seg = src[src.index("class Conv2d_BN"):src.index("class BiasFree_LayerNorm")] + \
+        src[src.index("class Illumination_Estimator"):src.index("class WMB(nn.Module)")]
+    ns = {"torch": torch, "nn": torch.nn, "F": torch.nn.functional}
+    exec(compile(seg, "WFB/model.py#a17", "exec"), ns)
+    out = {}
+    for tag, dim, fac, b, h, w in WFB_FF_CASES:
+        m = fill(ns["FeedForward"](dim, fac, True), 800 + dim)
+        x = rnd(51, f"wfb.{tag}.x", (b, dim, h, w))
+        with torch.no_grad():
+            y = m(x)
+            mine = R.wfb_feed_forward(x, sd_of(m), "")
+        log(f"  WFB FeedForward {tag} dim={dim} hidden={int(dim * fac)} {b}x{h}x{w}: oracle vs reference {maxabs(y, mine):.2e}")
+        assert maxabs(y, mine) < 2e-5
+        out[f"{tag}.out"] = y
+    for tag, mid, b, h, w in WFB_IE_CASES:
+        m = fill(ns["Illumination_Estimator"](mid), 900 + mid)
+        img = rnd(52, f"wfb.{tag}.img", (b, 3, h, w), 0.0, 1.0)
+        with torch.no_grad():
+            fea, imap = m(img)
+            mf, mm = R.illumination_estimator(img, sd_of(m), "")
+        log(f"  WFB Illumination_Estimator {tag} mid={mid} {b}x{h}x{w}: oracle vs reference {max(maxabs(fea, mf), maxabs(imap, mm)):.2e}")
+        assert max(maxabs(fea, mf), maxabs(imap, mm)) < 2e-5
+        out[f"{tag}.fea"], out[f"{tag}.map"] = fea, imap
+    save("wfb_extras", **out)
+
+
 def state_dict_keys(flca_mod):
     """Key names and shapes of the reference's state_dict (what test.py:88-91 loads strictly)."""
     import json
@@ -393,7 +428,7 @@ def main():
     ap.add_argument("--big", action="store_true", help="also run BASELINE configs 2-3 (minutes of CPU)")
     ap.add_argument("--only-keys", action="store_true", help="only (re)write state_dict_keys.json")
     ap.add_argument("--only-harness", action="store_true", help="only the evaluation-harness fixture (test.py helpers)")
-    ap.add_argument("--only-attenblock", action="store_true", help="only the Attenblock.LuminanceAwareMHSA fixture (a16)")
+    ap.add_argument("--only-attenblock", action="store_true", help="only the Attenblock.LuminanceAwareMHSA (a16) and WFB extras (a17) fixtures")
     ap.add_argument("--only-cfg4", action="store_true", help="only BASELINE config 4 (RawFormer-L, one 2848x4256 mosaic)")
     args = ap.parse_args()
     if args.only_keys:
@@ -408,6 +443,7 @@ def main():
         os.makedirs(GOLD, exist_ok=True)
         import_reference()
         attenblock()
+        wfb_extras()
         with open(os.path.join(GOLD, "PINNING.txt"), "a") as f:
             f.write("\n".join(LOG) + "\n")
         return
@@ -422,6 +458,7 @@ def main():
     per_op(*mods)
     whole_model(mods[0], args.big)
     attenblock()
+    wfb_extras()
     state_dict_keys(mods[0])
     with open(os.path.join(GOLD, "PINNING.txt"), "w") as f:
         f.write("# written by oracle/make_golden.py: reference (run on CPU here) vs oracle/rawformer_ref.py\n")

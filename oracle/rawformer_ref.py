@@ -424,3 +424,31 @@ def luminance_aware_mhsa(x: Tensor, luma: Tensor, p: Dict[str, Tensor], pre: str
     alpha = p.get(pre + "alpha")
     qkv = luma_film(qkv, gamma, beta, luma if alpha is not None else None, alpha)
     return F.conv2d(token_attention(qkv, heads), p[pre + "proj.weight"], p.get(pre + "proj.bias"))
+
+
+# ------------------------------------------------------------------------------------------
+# a17: WFB extras without Mamba (RawFomer_WFB_FFAB/model.py:17-87, 174-200), eval mode
+# ------------------------------------------------------------------------------------------
+def _conv_bn(x: Tensor, p: Dict[str, Tensor], pre: str, pad: int) -> Tensor:
+    """Conv2d_BN (model.py:17-25) in eval mode: depthwise conv without bias, then BatchNorm2d on running stats."""
+    c = x.shape[1]
+    y = F.conv2d(x, p[pre + "c.weight"], None, padding=pad, groups=c)
+    return F.batch_norm(y, p[pre + "bn.running_mean"], p[pre + "bn.running_var"], p[pre + "bn.weight"], p[pre + "bn.bias"],
+                        training=False, eps=1e-5)
+
+
+def wfb_feed_forward(x: Tensor, p: Dict[str, Tensor], pre: str) -> Tensor:
+    """FeedForward.forward (model.py:53-62), un-fused."""
+    hid = F.conv2d(x, p[pre + "project_in.weight"], p.get(pre + "project_in.bias"))
+    x1 = hid + _conv_bn(hid, p, pre + "rep_conv1.", 1) + _conv_bn(hid, p, pre + "rep_conv2.", 0)
+    x2 = F.conv2d(hid, p[pre + "dwconv.weight"], p.get(pre + "dwconv.bias"), padding=1, groups=hid.shape[1])
+    g = F.gelu(x2) * x1 + F.gelu(x1) * x2
+    return F.conv2d(g, p[pre + "project_out.weight"], p.get(pre + "project_out.bias")) + x
+
+
+def illumination_estimator(img: Tensor, p: Dict[str, Tensor], pre: str) -> Tuple[Tensor, Tensor]:
+    """Illumination_Estimator.forward (model.py:186-200)."""
+    inp = torch.cat([img, img.mean(dim=1, keepdim=True)], dim=1)
+    x1 = F.conv2d(inp, p[pre + "conv1.weight"], p[pre + "conv1.bias"])
+    fea = F.conv2d(x1, p[pre + "depth_conv.weight"], p[pre + "depth_conv.bias"], padding=2, groups=x1.shape[1])
+    return fea, F.conv2d(fea, p[pre + "conv2.weight"], p[pre + "conv2.bias"])

@@ -106,3 +106,24 @@ def atten_inputs(tag, dim, heads, b, h, w):
     x = rnd(f"atten.{tag}.x", (b, dim, h, w), seed=41)
     luma = rnd(f"atten.{tag}.luma", (b, 1, h, w), 0.0, 1.0, seed=42)
     return x, luma, params(atten_spec(dim, heads), seed=700 + dim + heads)
+
+
+# a17: WFB extras of tests/golden/wfb_extras.npz
+WFB_FF_CASES = (("ff32", 32, 2.0, 2, 16, 24), ("ff48", 48, 2.5, 1, 10, 14))     # tag, dim, expansion, B, h, w
+WFB_IE_CASES = (("ie32", 32, 2, 16, 24), ("ie40", 40, 1, 9, 14))                # tag, middle channels, B, h, w
+
+
+def wfb_ff_spec(dim, fac):
+    hid = int(dim * fac)
+    s = {"project_in.weight": (hid, dim, 1, 1), "project_in.bias": (hid,), "dwconv.weight": (hid, 1, 3, 3), "dwconv.bias": (hid,),
+         "project_out.weight": (dim, hid, 1, 1), "project_out.bias": (dim,)}
+    for name, k in (("rep_conv1", 3), ("rep_conv2", 1)):
+        s[f"{name}.c.weight"] = (hid, 1, k, k)
+        for leaf in ("weight", "bias", "running_mean", "running_var"):
+            s[f"{name}.bn.{leaf}"] = (hid,)
+    return s
+
+
+def wfb_ie_spec(mid):
+    return {"conv1.weight": (mid, 4, 1, 1), "conv1.bias": (mid,), "depth_conv.weight": (mid, 1, 5, 5), "depth_conv.bias": (mid,),
+            "conv2.weight": (3, mid, 1, 1), "conv2.bias": (3,)}
