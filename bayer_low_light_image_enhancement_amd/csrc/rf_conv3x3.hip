@@ -1,5 +1,10 @@
 // Dense 3x3 convolution (padding 1) as an implicit GEMM on the f32 matrix cores
-// (v_mfma_f32_16x16x4_f32; K = 4 input channels at one tap per instruction).
+// (v_mfma_f32_16x16x4_f32; K = 4 input channels per instruction), with the Winograd F(2,3) minimal filtering
+// algorithm along x: a pair of output pixels of one kernel row costs 4 products instead of 6,
+//   y0 = m0 + m1 + m2,  y1 = m1 - m2 - m3,   m = (G g) * (B^T d),
+//   G g = (g0, (g0+g1+g2)/2, (g0-g1+g2)/2, g2) is done when the weights are packed (rf_pack.hip),
+//   B^T d = (d0-d2, d1+d2, d2-d1, d1-d3) are 8 VALU operations per (k-set, input row) next to 8*NCO MFMAs,
+// so a chunk takes 2/3 of the MFMAs of the direct form for twice the accumulator registers.
 //
 // Workgroup = 4 waves; it owns a (4*RW rows) x (64/RW cols) pixel tile and NCO*16 output
 // channels, and is persistent over several such tiles.  Per 8-input-channel chunk the halo'd input tile and the matching slice of the
@@ -36,9 +41,9 @@ __global__ void __launch_bounds__(256, 2) conv3x3_kernel(Conv3x3Args a, int ngro
     constexpr int PS = ((TH + 2) * RS + 63) / 64 * 64;   // LDS plane stride in floats (multiple of 64)
     constexpr int NIN = KC * (TH + 2) * (TW + 2);       // staged input elements per chunk
     constexpr int EPT = (NIN + 255) / 256;              // ... per thread
-    constexpr int NW4 = 2 * 9 * NCO * 16;               // staged weight float4 per chunk
+    constexpr int NW4 = 2 * 12 * NCO * 16;              // staged weight float4 per chunk (12 transformed taps per k-set)
     constexpr int WPT = (NW4 + 255) / 256;
-    constexpr int BUF = KC * PS + 2 * 9 * NCO * 64;     // floats per LDS buffer
+    constexpr int BUF = KC * PS + 2 * 12 * NCO * 64;    // floats per LDS buffer
     __shared__ __attribute__((aligned(16))) float lds[2 * BUF];
 
     const int tid = threadIdx.x;
@@ -84,11 +89,11 @@ __global__ void __launch_bounds__(256, 2) conv3x3_kernel(Conv3x3Args a, int ngro
         const int idx = tid + 256 * i;
         const int l4 = idx % 16;
         const int t = (idx / 16) % NCO;
-        const int kt = idx / (16 * NCO);          // ks * 9 + tap
+        const int kt = idx / (16 * NCO);          // ks * 12 + dy * 4 + j
         const bool ok = idx < NW4 && t0 + t < NT;
         wvoff[i] = ok ? (unsigned)(((kt * NT + t0 + t) * 64 + l4 * 4) * 4) : OOB;
     }
-    const int w_chunk_bytes = 2 * 9 * NT * 64 * 4;
+    const int w_chunk_bytes = 2 * 12 * NT * 64 * 4;
     const size_t plane_bytes = (size_t)h * w * 4;      // one packed-resolution plane
 
     unsigned voff[EPT];       // current tile: byte offset inside the chunk's planes, OOB = zero
@@ -144,7 +149,7 @@ __global__ void __launch_bounds__(256, 2) conv3x3_kernel(Conv3x3Args a, int ngro
         }
     };
 
-    f32x4 acc[RPW][NCO][4];
+    f32x4 acc[RPW][NCO][2][4];   // [row group][output tile][pixel pair][Winograd product m0..m3]
 
     // ---- persistent over a contiguous range of tiles: the first chunk of the next tile is prefetched
     // behind the last MFMA block of the current one, so only the very first load is exposed
@@ -167,7 +172,7 @@ __global__ void __launch_bounds__(256, 2) conv3x3_kernel(Conv3x3Args a, int ngro
 #pragma unroll
             for (int t = 0; t < NCO; ++t)
 #pragma unroll
-                for (int g = 0; g < 4; ++g) acc[rr][t][g] = (f32x4){0.f, 0.f, 0.f, 0.f};
+                for (int g = 0; g < 8; ++g) acc[rr][t][g >> 2][g & 3] = (f32x4){0.f, 0.f, 0.f, 0.f};
         for (int ch = 0; ch < nchunks; ++ch) {
             const bool last = ch + 1 == nchunks;
             const bool more = !last || tile + nwg < tile_end;
@@ -185,20 +190,21 @@ __global__ void __launch_bounds__(256, 2) conv3x3_kernel(Conv3x3Args a, int ngro
                 for (int ir = 0; ir < RPW + 2; ++ir) {          // input row group ir feeds output row groups ir-2 .. ir
                     const float4 lo = *reinterpret_cast<const float4*>(lp + ir * RS);
                     const float4 hi = *reinterpret_cast<const float4*>(lp + ir * RS + 4);
-                    const float v[6] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y};
+                    // F(2,3) input transform of the two pixel pairs: B^T d = (d0 - d2, d1 + d2, d2 - d1, d1 - d3)
+                    const float d[2][4] = {{lo.x - lo.z, lo.y + lo.z, lo.z - lo.y, lo.y - lo.w},
+                                           {lo.z - hi.x, lo.w + hi.x, hi.x - lo.w, lo.w - hi.y}};
 #pragma unroll
                     for (int rr = 0; rr < RPW; ++rr) {
                         const int dy = ir - rr;
                         if (dy < 0 || dy > 2) continue;
 #pragma unroll
-                        for (int dx = 0; dx < 3; ++dx) {
-                            const float* wl = lds_w + ((ks * 9 + dy * 3 + dx) * NCO) * 64 + lane;
+                        for (int j4 = 0; j4 < 4; ++j4) {
+                            const float* wl = lds_w + ((ks * 12 + dy * 4 + j4) * NCO) * 64 + lane;
 #pragma unroll
                             for (int t = 0; t < NCO; ++t) {
                                 const float av = wl[t * 64];
-#pragma unroll
-                                for (int g = 0; g < 4; ++g)
-                                    acc[rr][t][g] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, v[g + dx], acc[rr][t][g], 0, 0, 0);
+                                acc[rr][t][0][j4] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, d[0][j4], acc[rr][t][0][j4], 0, 0, 0);
+                                acc[rr][t][1][j4] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, d[1][j4], acc[rr][t][1][j4], 0, 0, 0);
                             }
                         }
                     }
@@ -227,7 +233,9 @@ __global__ void __launch_bounds__(256, 2) conv3x3_kernel(Conv3x3Args a, int ngro
             const float bs = (a.bias && co < a.Cout) ? a.bias[co] : 0.f;
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
-                float u = acc[rr][t][g][r] + bs;
+                // F(2,3) output transform: y0 = m0 + m1 + m2, y1 = m1 - m2 - m3 for each pixel pair
+                const f32x4* mm = acc[rr][t][g >> 1];
+                float u = ((g & 1) ? (mm[1][r] - mm[2][r]) - mm[3][r] : (mm[0][r] + mm[1][r]) + mm[2][r]) + bs;
                 if (a.act == 1) u = u > 0.f ? u : 0.2f * u;
                 else if (a.act == 2) u = fmaxf(u, 0.f);
                 if (a.clamp_out) u = fminf(fmaxf(u, 0.f), 1.f);
@@ -302,7 +310,7 @@ static void launch_rw(const Conv3x3Args& a, int ngroups, int vec, hipStream_t st
     // (LDS and registers: 2 per CU at NCO >= 3, 3 at NCO = 2, 4 at NCO = 1), each with the same number of tiles.
     const int lrw = a.w > 32 ? 0 : (a.w > 16 ? 1 : 2);
     // few output channels (NCO <= 2): every wave takes two pixel rows (8x64 tile), like NCO = 4 in MFMAs per barrier
-    constexpr int RPW2 = NCO <= 2 ? 2 : 1;
+    constexpr int RPW2 = NCO == 1 ? 2 : 1;    // (NCO = 2 with two rows would need 128 + 128 accumulator/staging registers: spills)
     const int rpw = (lrw == 0 && a.h >= 8) ? RPW2 : 1;
     const int txs = cdiv(a.w, 64 >> lrw), tys = cdiv(a.h, (4 << lrw) * rpw);
     const int ntiles = txs * tys;
@@ -333,7 +341,7 @@ int launch_conv3x3(const Conv3x3Args& a, hipStream_t st) {
     const int ngroups = cdiv(NT, nco);
     const int vec = (a.w % 4 == 0) && aligned16(a.out) && (a.out_bstride % 4 == 0);
     char key[64];
-    snprintf(key, sizeof(key), "conv3x3_kernel<%d, %d, %d>", nco, a.w > 32 ? 0 : (a.w > 16 ? 1 : 2), (nco <= 2 && a.w > 32 && a.h >= 8) ? 2 : 1);
+    snprintf(key, sizeof(key), "conv3x3_kernel<%d, %d, %d>", nco, a.w > 32 ? 0 : (a.w > 16 ? 1 : 2), (nco == 1 && a.w > 32 && a.h >= 8) ? 2 : 1);
     const double px = (double)a.B * a.h * a.w;
     ProfScope prof(st, key, 18.0 * a.Cin * a.Cout * px, 4.0 * px * (a.Cin + a.Cout));
     switch (nco) {
