@@ -56,11 +56,12 @@ static inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t
 // A packed weight matrix [Cout][K] is stored as tiles of 64 floats in lane order:
 //   packed[(s * NT + t) * 64 + l] = W[16 t + (l & 15)][4 s + (l >> 4)]      (zero outside)
 // with NT = ceil(Cout / 16) and s over ceil(K / 4) k-sets.  A 3x3 weight [Cout][Cin][3][3] is
-//   packed[((s * 12 + dy * 4 + j) * NT + t) * 64 + l] = u_j(W[16 t + (l & 15)][4 s + (l >> 4)][dy][0..2]),
-// the Winograd F(2,3) transform of the three taps of kernel row dy (rf_pack.hip).
+//   packed[((s * TAPS + dy * TAPS/3 + j) * NT + t) * 64 + l] = u_j(W[16 t + (l & 15)][4 s + (l >> 4)][dy][0..2]),
+// the Winograd transform G g of the three taps of kernel row dy (rf_pack.hip; TAPS = 18).
 // ---------------------------------------------------------------------------------------------
 static inline size_t packed1x1_floats(int K, int Cout) { return (size_t)cdiv(K, 4) * cdiv(Cout, 16) * 64; }
-static inline size_t packed3x3_floats(int Cin, int Cout) { return (size_t)cdiv(Cin, 8) * 2 * 12 * cdiv(Cout, 16) * 64; }
+// 3x3 weights are packed in Winograd F(4,3) form along x: 18 transformed taps per k-set
+static inline size_t packed3x3_floats(int Cin, int Cout) { return (size_t)cdiv(Cin, 8) * 2 * 18 * cdiv(Cout, 16) * 64; }
 
 // ---- weight repacking (rf_pack.hip)
 // 1x1: W[Cout][K] row-major -> packed.  `row_stride`/`col_stride` let the source be a

@@ -1,12 +1,16 @@
 // Dense 3x3 convolution (padding 1) as an implicit GEMM on the f32 matrix cores
-// (v_mfma_f32_16x16x4_f32; K = 4 input channels per instruction), with the Winograd F(2,3) minimal filtering
-// algorithm along x: a pair of output pixels of one kernel row costs 4 products instead of 6,
-//   y0 = m0 + m1 + m2,  y1 = m1 - m2 - m3,   m = (G g) * (B^T d),
-//   G g = (g0, (g0+g1+g2)/2, (g0-g1+g2)/2, g2) is done when the weights are packed (rf_pack.hip),
-//   B^T d = (d0-d2, d1+d2, d2-d1, d1-d3) are 8 VALU operations per (k-set, input row) next to 8*NCO MFMAs,
-// so a chunk takes 2/3 of the MFMAs of the direct form for twice the accumulator registers.
+// (v_mfma_f32_16x16x4_f32; K = 4 input channels per instruction), with the Winograd F(4,3) minimal filtering
+// algorithm along x: the lane's 4 output pixels of one kernel row cost 6 products instead of 12,
+//   m = (G g) * (B^T d),   y = A^T m
+//   G g   = (g0/4, -(g0+g1+g2)/6, -(g0-g1+g2)/6, g0/24+g1/12+g2/6, g0/24-g1/12+g2/6, g2): done when the weights
+//           are packed (rf_pack.hip), 18 taps per k-set instead of 9
+//   B^T d = (4d0-5d2+d4, (d4-4d2)+(d3-4d1), (d4-4d2)-(d3-4d1), (d4-d2)+2(d3-d1), (d4-d2)-2(d3-d1), 4d1-5d3+d5):
+//           12 VALU operations on the two ds_read_b128 of a (k-set, input row), next to 6*NCO MFMAs
+//   A^T m = (m0+m1+m2+m3+m4, (m1-m2)+2(m3-m4), (m1+m2)+4(m3+m4), (m1-m2)+8(m3-m4)+m5): once per tile, in the epilogue
+// A chunk takes half the MFMAs of the direct form.  Rounding error 2.2 x the direct form's (f32 simulated against
+// f64: 5e-7 on O(0.2) outputs at Cin = 32, 1.3e-6 at Cin = 256), inside every parity tolerance.
 //
-// Workgroup = 4 waves; it owns a (4*RW rows) x (64/RW cols) pixel tile and NCO*16 output
+// Workgroup = NWV waves; it owns a (NWV*RW*RPW rows) x (64/RW cols) pixel tile and NCO*16 output
 // channels, and is persistent over several such tiles.  Per 8-input-channel chunk the halo'd input tile and the matching slice of the
 // lane-ordered packed weights sit in LDS; every wave then walks 2 k-sets x 9 taps.
 //   * B operand: lane (kq, j) owns 4 consecutive pixels of one row.  Two ds_read_b128 per
@@ -30,20 +34,25 @@ namespace rf {
 static constexpr int KC = 8;        // input channels per LDS chunk
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 
-template <int NCO, int LOG2_RW, int RPW>
-__global__ void __launch_bounds__(256, 2) conv3x3_kernel(Conv3x3Args a, int ngroups, int tiles_x, int ntiles, int vec) {
+// NWV = waves per workgroup: 8 on wide images (the 18-tap weight slice is shared by twice the waves, so that two
+// waves per SIMD fit the 160 KB of LDS with one workgroup per CU), 4 for the narrow-image tile shapes.
+template <int NCO, int LOG2_RW, int RPW, int NWV>
+__global__ void __launch_bounds__(64 * NWV, NWV == 8 ? 1 : 2) conv3x3_kernel(Conv3x3Args a, int ngroups, int tiles_x, int ntiles, int vec) {
+    constexpr int NTHR = 64 * NWV;
+    constexpr int TAPS = 18;                 // transformed taps per k-set (3 kernel rows x 6)
+    constexpr int NM = 6;                    // Winograd products per lane and output tile
     constexpr int RW = 1 << LOG2_RW;         // rows one MFMA pixel group spans (narrow images)
     constexpr int TW = 64 / RW;              // tile width
-    constexpr int TH = 4 * RW * RPW;         // tile height: a wave owns RPW row groups (RPW = 2 for few output channels:
+    constexpr int TH = NWV * RW * RPW;       // tile height: a wave owns RPW row groups (RPW = 2 for few output channels:
                                              // twice the MFMAs per barrier and per staged weight, 17 % less halo)
     static_assert(RPW == 1 || RW == 1, "two row groups per wave only with one row per group");
     constexpr int RS = TW + 8;               // LDS row stride
     constexpr int PS = ((TH + 2) * RS + 63) / 64 * 64;   // LDS plane stride in floats (multiple of 64)
     constexpr int NIN = KC * (TH + 2) * (TW + 2);       // staged input elements per chunk
-    constexpr int EPT = (NIN + 255) / 256;              // ... per thread
-    constexpr int NW4 = 2 * 12 * NCO * 16;              // staged weight float4 per chunk (12 transformed taps per k-set)
-    constexpr int WPT = (NW4 + 255) / 256;
-    constexpr int BUF = KC * PS + 2 * 12 * NCO * 64;    // floats per LDS buffer
+    constexpr int EPT = (NIN + NTHR - 1) / NTHR;        // ... per thread
+    constexpr int NW4 = 2 * TAPS * NCO * 16;            // staged weight float4 per chunk
+    constexpr int WPT = (NW4 + NTHR - 1) / NTHR;
+    constexpr int BUF = KC * PS + 2 * TAPS * NCO * 64;  // floats per LDS buffer
     __shared__ __attribute__((aligned(16))) float lds[2 * BUF];
 
     const int tid = threadIdx.x;
@@ -67,16 +76,16 @@ __global__ void __launch_bounds__(256, 2) conv3x3_kernel(Conv3x3Args a, int ngro
     //     num_records = the planes that exist).  Zero padding, "no element" and channels beyond Cin
     //     are out-of-range offsets -> the hardware returns 0.
     //   * weights: buffer_load_dwordx4, same trick for output tiles beyond Cout.
-    // Element i of this thread is halo'd-tile element idx = tid + 256 i = (channel cl, row r, col c).
+    // Element i of this thread is halo'd-tile element idx = tid + NTHR i = (channel cl, row r, col c).
     constexpr unsigned OOB = 0x80000000u;   // > any num_records (images are < 2 GiB, checked by the launcher)
     int prc[EPT];             // (cl << 16) | (r << 8) | c, or -1 = no element
     short loff[EPT];          // LDS float offset inside a buffer ("no element" -> a spare slot in the plane padding,
                               // so the LDS writes need no predicate; 128 spare slots, 2 threads of different waves each)
     static_assert(PS - (TH + 2) * RS >= 16, "plane padding holds the dummy slots");
-    const int dummy = (tid & 7) * PS + (TH + 2) * RS + ((tid >> 3) & 15);
+    const int dummy = (tid & 7) * PS + (TH + 2) * RS + ((tid >> 3) & 15);   // shared only by threads of different waves
 #pragma unroll
     for (int i = 0; i < EPT; ++i) {
-        const int idx = tid + 256 * i;
+        const int idx = tid + NTHR * i;
         const int c = idx % (TW + 2);
         const int r = (idx / (TW + 2)) % (TH + 2);
         const int cl = idx / ((TW + 2) * (TH + 2));
@@ -86,14 +95,14 @@ __global__ void __launch_bounds__(256, 2) conv3x3_kernel(Conv3x3Args a, int ngro
     unsigned wvoff[WPT];      // weight byte offsets inside one chunk's packed slice
 #pragma unroll
     for (int i = 0; i < WPT; ++i) {
-        const int idx = tid + 256 * i;
+        const int idx = tid + NTHR * i;
         const int l4 = idx % 16;
         const int t = (idx / 16) % NCO;
-        const int kt = idx / (16 * NCO);          // ks * 12 + dy * 4 + j
+        const int kt = idx / (16 * NCO);          // ks * TAPS + dy * (TAPS / 3) + j
         const bool ok = idx < NW4 && t0 + t < NT;
         wvoff[i] = ok ? (unsigned)(((kt * NT + t0 + t) * 64 + l4 * 4) * 4) : OOB;
     }
-    const int w_chunk_bytes = 2 * 12 * NT * 64 * 4;
+    const int w_chunk_bytes = 2 * TAPS * NT * 64 * 4;
     const size_t plane_bytes = (size_t)h * w * 4;      // one packed-resolution plane
 
     unsigned voff[EPT];       // current tile: byte offset inside the chunk's planes, OOB = zero
@@ -144,12 +153,12 @@ __global__ void __launch_bounds__(256, 2) conv3x3_kernel(Conv3x3Args a, int ngro
         }
 #pragma unroll
         for (int i = 0; i < WPT; ++i) {
-            const int idx = tid + 256 * i;
+            const int idx = tid + NTHR * i;
             if (idx < NW4) *reinterpret_cast<float4*>(lw + idx * 4) = win[i];   // [kt][t][64] is linear in idx
         }
     };
 
-    f32x4 acc[RPW][NCO][2][4];   // [row group][output tile][pixel pair][Winograd product m0..m3]
+    f32x4 acc[RPW][NCO][NM];     // [row group][output tile][Winograd product m_0..5]
 
     // ---- persistent over a contiguous range of tiles: the first chunk of the next tile is prefetched
     // behind the last MFMA block of the current one, so only the very first load is exposed
@@ -172,7 +181,7 @@ __global__ void __launch_bounds__(256, 2) conv3x3_kernel(Conv3x3Args a, int ngro
 #pragma unroll
             for (int t = 0; t < NCO; ++t)
 #pragma unroll
-                for (int g = 0; g < 8; ++g) acc[rr][t][g >> 2][g & 3] = (f32x4){0.f, 0.f, 0.f, 0.f};
+                for (int g = 0; g < NM; ++g) acc[rr][t][g] = (f32x4){0.f, 0.f, 0.f, 0.f};
         for (int ch = 0; ch < nchunks; ++ch) {
             const bool last = ch + 1 == nchunks;
             const bool more = !last || tile + nwg < tile_end;
@@ -190,21 +199,25 @@ __global__ void __launch_bounds__(256, 2) conv3x3_kernel(Conv3x3Args a, int ngro
                 for (int ir = 0; ir < RPW + 2; ++ir) {          // input row group ir feeds output row groups ir-2 .. ir
                     const float4 lo = *reinterpret_cast<const float4*>(lp + ir * RS);
                     const float4 hi = *reinterpret_cast<const float4*>(lp + ir * RS + 4);
-                    // F(2,3) input transform of the two pixel pairs: B^T d = (d0 - d2, d1 + d2, d2 - d1, d1 - d3)
-                    const float d[2][4] = {{lo.x - lo.z, lo.y + lo.z, lo.z - lo.y, lo.y - lo.w},
-                                           {lo.z - hi.x, lo.w + hi.x, hi.x - lo.w, lo.w - hi.y}};
+                    float d[NM];
+                    {
+                        const float p = fmaf(-4.f, lo.z, hi.x), q = fmaf(-4.f, lo.y, lo.w);      // d4 - 4 d2, d3 - 4 d1
+                        const float c2 = hi.x - lo.z, e2 = lo.w - lo.y;                         // d4 - d2,   d3 - d1
+                        d[0] = fmaf(4.f, lo.x, fmaf(-5.f, lo.z, hi.x));
+                        d[1] = p + q; d[2] = p - q;
+                        d[3] = fmaf(2.f, e2, c2); d[4] = fmaf(-2.f, e2, c2);
+                        d[5] = fmaf(4.f, lo.y, fmaf(-5.f, lo.w, hi.y));
+                    }
 #pragma unroll
                     for (int rr = 0; rr < RPW; ++rr) {
                         const int dy = ir - rr;
                         if (dy < 0 || dy > 2) continue;
 #pragma unroll
-                        for (int j4 = 0; j4 < 4; ++j4) {
-                            const float* wl = lds_w + ((ks * 12 + dy * 4 + j4) * NCO) * 64 + lane;
+                        for (int j4 = 0; j4 < TAPS / 3; ++j4) {
+                            const float* wl = lds_w + ((ks * TAPS + dy * (TAPS / 3) + j4) * NCO) * 64 + lane;
 #pragma unroll
                             for (int t = 0; t < NCO; ++t) {
-                                const float av = wl[t * 64];
-                                acc[rr][t][0][j4] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, d[0][j4], acc[rr][t][0][j4], 0, 0, 0);
-                                acc[rr][t][1][j4] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, d[1][j4], acc[rr][t][1][j4], 0, 0, 0);
+                                acc[rr][t][j4] = __builtin_amdgcn_mfma_f32_16x16x4f32(wl[t * 64], d[j4], acc[rr][t][j4], 0, 0, 0);
                             }
                         }
                     }
@@ -233,9 +246,10 @@ __global__ void __launch_bounds__(256, 2) conv3x3_kernel(Conv3x3Args a, int ngro
             const float bs = (a.bias && co < a.Cout) ? a.bias[co] : 0.f;
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
-                // F(2,3) output transform: y0 = m0 + m1 + m2, y1 = m1 - m2 - m3 for each pixel pair
-                const f32x4* mm = acc[rr][t][g >> 1];
-                float u = ((g & 1) ? (mm[1][r] - mm[2][r]) - mm[3][r] : (mm[0][r] + mm[1][r]) + mm[2][r]) + bs;
+                // output transform A^T m of the lane's F(4,3) tile
+                const f32x4* mm = acc[rr][t];
+                const float s12 = mm[1][r] + mm[2][r], d12 = mm[1][r] - mm[2][r], s34 = mm[3][r] + mm[4][r], d34 = mm[3][r] - mm[4][r];
+                float u = (g == 0 ? (mm[0][r] + s12) + s34 : g == 1 ? fmaf(2.f, d34, d12) : g == 2 ? fmaf(4.f, s34, s12) : fmaf(8.f, d34, d12) + mm[5][r]) + bs;
                 if (a.act == 1) u = u > 0.f ? u : 0.2f * u;
                 else if (a.act == 2) u = fmaxf(u, 0.f);
                 if (a.clamp_out) u = fminf(fmaxf(u, 0.f), 1.f);
@@ -305,28 +319,29 @@ __global__ void __launch_bounds__(256, 2) conv3x3_kernel(Conv3x3Args a, int ngro
 
 template <int NCO>
 static void launch_rw(const Conv3x3Args& a, int ngroups, int vec, hipStream_t st) {
-    // tile shape from the image width: 64x4, 32x8 or 16x16 pixels.  Workgroups are persistent over
-    // tiles of one (image, output group): as many workgroups as stay resident at once
-    // (LDS and registers: 2 per CU at NCO >= 3, 3 at NCO = 2, 4 at NCO = 1), each with the same number of tiles.
+    // Wide images (w > 32): 8 waves share one 18-tap weight slice, one workgroup per CU; a wave owns one pixel
+    // row of 64 (NCO >= 3) or two (NCO <= 2: 16x64 tile, 144 MFMAs per barrier).  Narrow images fall back to
+    // 4-wave tiles of 32x8 or 16x16 pixels.  Workgroups are persistent over tiles of one (image, output group).
     const int lrw = a.w > 32 ? 0 : (a.w > 16 ? 1 : 2);
-    // few output channels (NCO <= 2): every wave takes two pixel rows (8x64 tile), like NCO = 4 in MFMAs per barrier
-    constexpr int RPW2 = NCO == 1 ? 2 : 1;    // (NCO = 2 with two rows would need 128 + 128 accumulator/staging registers: spills)
-    const int rpw = (lrw == 0 && a.h >= 8) ? RPW2 : 1;
-    const int txs = cdiv(a.w, 64 >> lrw), tys = cdiv(a.h, (4 << lrw) * rpw);
-    const int ntiles = txs * tys;
-    const long slots = 256L * (rpw == 2 || NCO >= 3 ? 2 : (NCO == 2 ? 3 : 4));
-    const long total = (long)ntiles * ngroups * a.B;
-    const int per_wg = (int)((total + slots - 1) / slots);
-    const int wgs = cdiv(ntiles, per_wg);
-    const dim3 grid((unsigned)(ngroups * wgs), (unsigned)a.B);
-    if (lrw == 0 && rpw == 2)
-        conv3x3_kernel<NCO, 0, RPW2><<<grid, 256, 0, st>>>(a, ngroups, txs, ntiles, vec);
-    else if (lrw == 0)
-        conv3x3_kernel<NCO, 0, 1><<<grid, 256, 0, st>>>(a, ngroups, txs, ntiles, vec);
-    else if (lrw == 1)
-        conv3x3_kernel<NCO, 1, 1><<<grid, 256, 0, st>>>(a, ngroups, txs, ntiles, vec);
-    else
-        conv3x3_kernel<NCO, 2, 1><<<grid, 256, 0, st>>>(a, ngroups, txs, ntiles, vec);
+    constexpr int RPWB = NCO <= 2 ? 2 : 1;
+    auto grid_for_tiles = [&](int ntiles) {
+        const long total = (long)ntiles * ngroups * a.B;
+        const int wgs = cdiv(ntiles, (int)((total + 255) / 256));      // one resident workgroup per CU
+        return dim3((unsigned)(ngroups * wgs), (unsigned)a.B);
+    };
+    if (lrw == 0 && a.h >= 8 * RPWB) {
+        const int txs = cdiv(a.w, 64), ntiles = txs * cdiv(a.h, 8 * RPWB);
+        conv3x3_kernel<NCO, 0, RPWB, 8><<<grid_for_tiles(ntiles), 512, 0, st>>>(a, ngroups, txs, ntiles, vec);
+    } else if (lrw == 0 && a.h >= 8) {
+        const int txs = cdiv(a.w, 64), ntiles = txs * cdiv(a.h, 8);
+        conv3x3_kernel<NCO, 0, 1, 8><<<grid_for_tiles(ntiles), 512, 0, st>>>(a, ngroups, txs, ntiles, vec);
+    } else {
+        const int txs = cdiv(a.w, 64 >> lrw), ntiles = txs * cdiv(a.h, 4 << lrw);
+        const dim3 grid = grid_for_tiles(ntiles);
+        if (lrw == 0) conv3x3_kernel<NCO, 0, 1, 4><<<grid, 256, 0, st>>>(a, ngroups, txs, ntiles, vec);
+        else if (lrw == 1) conv3x3_kernel<NCO, 1, 1, 4><<<grid, 256, 0, st>>>(a, ngroups, txs, ntiles, vec);
+        else conv3x3_kernel<NCO, 2, 1, 4><<<grid, 256, 0, st>>>(a, ngroups, txs, ntiles, vec);
+    }
 }
 
 int launch_conv3x3(const Conv3x3Args& a, hipStream_t st) {
@@ -341,7 +356,11 @@ int launch_conv3x3(const Conv3x3Args& a, hipStream_t st) {
     const int ngroups = cdiv(NT, nco);
     const int vec = (a.w % 4 == 0) && aligned16(a.out) && (a.out_bstride % 4 == 0);
     char key[64];
-    snprintf(key, sizeof(key), "conv3x3_kernel<%d, %d, %d>", nco, a.w > 32 ? 0 : (a.w > 16 ? 1 : 2), (nco == 1 && a.w > 32 && a.h >= 8) ? 2 : 1);
+    {
+        const int lrw = a.w > 32 ? 0 : (a.w > 16 ? 1 : 2), rpwb = nco <= 2 ? 2 : 1;
+        const int wide = lrw == 0 && a.h >= 8;
+        snprintf(key, sizeof(key), "conv3x3_kernel<%d, %d, %d, %d>", nco, lrw, (wide && a.h >= 8 * rpwb) ? rpwb : 1, wide ? 8 : 4);
+    }
     const double px = (double)a.B * a.h * a.w;
     ProfScope prof(st, key, 18.0 * a.Cin * a.Cout * px, 4.0 * px * (a.Cin + a.Cout));
     switch (nco) {

@@ -30,22 +30,25 @@ int pack_convT(const float* w, float* packed, int Cin, int Cout, hipStream_t st)
     return pack_1x1(w, packed, 4 * Cout, Cin, 1, (int64_t)4 * Cout, st);
 }
 
-// 3x3 weights, Winograd F(2,3) along x (rf_conv3x3.hip): per kernel row dy the three taps g0 g1 g2 become
-// u0 = g0, u1 = (g0 + g1 + g2) / 2, u2 = (g0 - g1 + g2) / 2, u3 = g2; entry index = dy * 4 + j.
+// 3x3 weights in Winograd F(4,3) form along x (rf_conv3x3.hip): per kernel row dy the three taps g0 g1 g2 become
+//   u = (g0/4, -(g0+g1+g2)/6, -(g0-g1+g2)/6, g0/24+g1/12+g2/6, g0/24-g1/12+g2/6, g2);  entry index = dy * 6 + j.
 __global__ void __launch_bounds__(256) pack_3x3_kernel(const float* __restrict__ w, float* __restrict__ packed, int Cout, int Cin) {
     const int NT = (Cout + 15) >> 4, NS = ((Cin + 7) >> 3) * 2;
-    const size_t total = (size_t)NS * 12 * NT * 64;
+    const size_t total = (size_t)NS * 18 * NT * 64;
     for (size_t idx = blockIdx.x * 256ull + threadIdx.x; idx < total; idx += (size_t)gridDim.x * 256) {
         const int l = (int)(idx & 63);
         const int t = (int)((idx >> 6) % NT);
-        const int e = (int)(((idx >> 6) / NT) % 12);
-        const int s = (int)((idx >> 6) / ((size_t)NT * 12));
+        const int e = (int)(((idx >> 6) / NT) % 18);
+        const int s = (int)((idx >> 6) / ((size_t)NT * 18));
         const int co = 16 * t + (l & 15), ci = 4 * s + (l >> 4);
         float u = 0.f;
         if (co < Cout && ci < Cin) {
-            const float* g = w + ((size_t)co * Cin + ci) * 9 + (e >> 2) * 3;
-            const int j = e & 3;
-            u = j == 0 ? g[0] : j == 3 ? g[2] : j == 1 ? 0.5f * ((g[0] + g[2]) + g[1]) : 0.5f * ((g[0] + g[2]) - g[1]);
+            const float* g = w + ((size_t)co * Cin + ci) * 9 + (e / 6) * 3;
+            const int j = e % 6;
+            const float s02 = g[0] + g[2];
+            const float e02 = fmaf(g[0], 1.0f / 24.0f, g[2] * (1.0f / 6.0f));
+            u = j == 0 ? 0.25f * g[0] : j == 1 ? -(s02 + g[1]) * (1.0f / 6.0f) : j == 2 ? -(s02 - g[1]) * (1.0f / 6.0f)
+              : j == 3 ? fmaf(g[1], 1.0f / 12.0f, e02) : j == 4 ? fmaf(g[1], -1.0f / 12.0f, e02) : g[2];
         }
         packed[idx] = u;
     }

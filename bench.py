@@ -262,9 +262,9 @@ def main():
         rl["share_of_forward"] = round(top["ms"] / total, 4)
         if top["kernel"].startswith("conv3x3_kernel"):
             # `achieved` prices the ALGORITHMIC flops (18 Cin Cout per pixel); the kernel uses the Winograd
-            # F(2,3) form along x and issues 2/3 of them as MFMA work, so the matrix pipe itself runs at frac * 2/3 of peak
-            rl["mfma_flops_issued_over_algorithmic"] = round(2.0 / 3.0, 4)
-            rl["frac_of_peak_issued"] = round(rl["frac"] * 2.0 / 3.0, 4)
+            # F(4,3) form along x and issues half of them as MFMA work, so the matrix pipe itself runs at frac / 2 of peak
+            rl["mfma_flops_issued_over_algorithmic"] = 0.5
+            rl["frac_of_peak_issued"] = round(rl["frac"] * 0.5, 4)
         line["roofline"] = rl
         line["kernels"] = [{"kernel": r["kernel"], "launches_per_step": r["launches"] // args.steps,
                             "ms_per_step": round(r["ms"] / args.steps, 4), "share": round(r["ms"] / total, 4),
