@@ -71,6 +71,8 @@ SIGNATURES = {
     "rf_luma_film": (_i, [_vp, _vp, _vp, C.c_longlong, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
     "rf_dwgate3x3": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
     "rf_dwconv5x5": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
+    "rf_upcat_scratch_bytes": (_i, [_i, _psz]),
+    "rf_upcat": (_i, [_vp] * 8 + [_i, _i, _i, _i, _vp]),
 }
 
 _lib = None

@@ -360,4 +360,17 @@ int rf_flca_guidance(const float* packed, float* guide, void* scratch, int B, in
     return launch_guidance_level((const float*)scratch, guide, B, H, W, hf, wf, st);
 }
 
+int rf_upcat_scratch_bytes(int C, size_t* bytes) {
+    RF_CHECK_ARG(bytes && C > 0 && C % 4 == 0, "upcat_scratch_bytes: bad arguments");
+    *bytes = upcat_packed_floats(C) * sizeof(float);
+    return RF_OK;
+}
+
+int rf_upcat(const float* x, const float* skip, float* out, const float* up_w, const float* up_b, const float* cr_w, const float* cr_b,
+             void* scratch, int B, int C, int h, int w, void* stream) {
+    RF_CHECK_ARG(x && skip && out && up_w && cr_w && scratch && aligned16(scratch), "upcat: bad arguments");
+    hipStream_t st = (hipStream_t)stream;
+    RF_TRY(pack_upcat(up_w, up_b, cr_w, cr_b, (float*)scratch, C, st));
+    return launch_upcat(x, skip, out, (const float*)scratch, B, C, h, w, st);
+}
 }  // extern "C"

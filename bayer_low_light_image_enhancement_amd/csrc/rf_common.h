@@ -70,6 +70,12 @@ int pack_1x1(const float* w, float* packed, int Cout, int K, int64_t row_stride,
 int pack_3x3(const float* w, float* packed, int Cout, int Cin, hipStream_t st);
 int pack_convT(const float* w, float* packed, int Cin, int Cout, hipStream_t st);
 
+// ---- decoder step ConvTranspose2d(2C,C,2,2) + cat skip + Conv2d(2C,C,1) on composed weights (rf_upcat.hip)
+size_t upcat_packed_floats(int C);
+int pack_upcat(const float* up_w, const float* up_b, const float* cr_w, const float* cr_b, float* packed, int C, hipStream_t st);
+bool upcat_supported(int C, int h, int w, const void* x, const void* skip, const void* out);
+int launch_upcat(const float* x, const float* skip, float* out, const float* packed, int B, int C, int h, int w, hipStream_t st);
+
 // ---- conv1x1 (rf_conv1x1.hip)
 struct Conv1x1Args {
     const float* x1;       // first source, channel 0 of image 0

@@ -37,7 +37,7 @@ typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 // NWV = waves per workgroup: 8 on wide images (the 18-tap weight slice is shared by twice the waves, so that two
 // waves per SIMD fit the 160 KB of LDS with one workgroup per CU), 4 for the narrow-image tile shapes.
 template <int NCO, int LOG2_RW, int RPW, int NWV>
-__global__ void __launch_bounds__(64 * NWV, NWV == 8 ? 1 : 2) conv3x3_kernel(Conv3x3Args a, int ngroups, int tiles_x, int ntiles, int vec) {
+__global__ void __launch_bounds__(64 * NWV, (NWV == 8 || NCO >= 3) ? 1 : 2) conv3x3_kernel(Conv3x3Args a, int ngroups, int tiles_x, int ntiles, int vec) {
     constexpr int NTHR = 64 * NWV;
     constexpr int TAPS = 18;                 // transformed taps per k-set (3 kernel rows x 6)
     constexpr int NM = 6;                    // Winograd products per lane and output tile

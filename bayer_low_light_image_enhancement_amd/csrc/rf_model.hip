@@ -37,6 +37,7 @@ struct rf_handle {
     std::vector<PackItem> packs;
     std::unordered_map<std::string, int> pack_index;   // weight name -> packs[]
     size_t packed_floats = 0;
+    size_t upcat_offset[3] = {0, 0, 0};   // composed decoder-step weights (rf_upcat.hip), floats into the packed buffer
     const float* packed = nullptr;   // caller memory, valid after rf_pack_params
 };
 
@@ -280,8 +281,10 @@ int rf_create(const rf_config* cfg, rf_handle** out) {
         add_param(h, u + ".bias", {C});
         add_param(h, r + ".weight", {C, 2 * C, 1, 1});
         add_param(h, r + ".bias", {C});
-        add_pack(h, u + ".weight", PK_CONVT);
-        add_pack(h, r + ".weight", PK_1x1);
+        add_pack(h, u + ".weight", PK_CONVT);      // the two-kernel form stays available for widths that are not
+        add_pack(h, r + ".weight", PK_1x1);        // multiples of 4 (e.g. level 3 of a 1424 x 2128 frame)
+        h->upcat_offset[i - 1] = h->packed_floats;
+        h->packed_floats += align_up(upcat_packed_floats(C), 64);
         add_stage(h, 4 + i, C, cfg->heads[lvl]);
     }
     add_param(h, "conv_out.weight", {4 * cfg->out_channels, d, 3, 3});
@@ -355,6 +358,11 @@ int rf_pack_params(rf_handle* h, void* packed_dev, size_t bytes, void* stream) {
         else rc = pack_convT(p.ptr, base + it.offset, (int)p.shape[0], (int)p.shape[1], st);
         if (rc) return rc;
     }
+    for (int i = 1; i <= 3; ++i) {
+        const int C = h->cfg.dim << (3 - i);
+        const std::string u = "up" + std::to_string(i), r = "channel_reduce" + std::to_string(i);
+        RF_TRY(pack_upcat(P(h, u + ".weight"), P(h, u + ".bias"), P(h, r + ".weight"), P(h, r + ".bias"), base + h->upcat_offset[i - 1], C, st));
+    }
     h->packed = base;
     return RF_OK;
 }
@@ -419,6 +427,12 @@ int rf_forward(rf_handle* h, const float* in, float* out, void* workspace, size_
     for (int i = 1; i <= 3; ++i) {
         const int lvl = 3 - i, C = d << lvl, hh = H >> lvl, ww = W >> lvl, Pn = hh * ww;
         const std::string u = "up" + std::to_string(i), r = "channel_reduce" + std::to_string(i);
+        if (upcat_supported(C, hh / 2, ww / 2, ws + p.tB, skip[lvl], ws + p.tA) && getenv("RF_NO_UPCAT") == nullptr) {
+            // ConvTranspose2d + cat + 1x1 as one kernel on composed weights: `up` never reaches HBM
+            RF_TRY(launch_upcat(ws + p.tB, skip[lvl], ws + p.tA, h->packed + h->upcat_offset[i - 1], B, C, hh / 2, ww / 2, st));
+            RF_TRY(run_stage(h, 4 + i, lvl, ws + p.tA, ws + p.tB, ws, p, B, H, W, st));
+            continue;
+        }
         Conv1x1Args up{};
         up.x1 = ws + p.tB; up.C1 = 2 * C; up.x1_bstride = (int64_t)2 * C * (Pn / 4);
         up.wp = PK(h, u + ".weight"); up.bias = P(h, u + ".bias");

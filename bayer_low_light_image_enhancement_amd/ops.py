@@ -439,3 +439,23 @@ def illumination_estimator(img: torch.Tensor, params, prefix: str = "") -> Tuple
     x1 = conv1x1(xin, wf, params.get(prefix + "conv1.bias"))
     fea = dwconv5x5(x1, params[prefix + "depth_conv.weight"], params.get(prefix + "depth_conv.bias"))
     return fea, conv1x1(fea, params[prefix + "conv2.weight"], params.get(prefix + "conv2.bias"))
+
+
+def upsample_cat_reduce(x: torch.Tensor, skip: torch.Tensor, up_w: torch.Tensor, up_b: Optional[torch.Tensor],
+                        cr_w: torch.Tensor, cr_b: Optional[torch.Tensor]) -> torch.Tensor:
+    """Decoder step ``channel_reduce(cat[up(x), skip])`` (RawFomer_WFB_FFAB/model.py:494-503) as one kernel on composed
+    weights: ``x`` [B,2C,h,w], ``skip`` [B,C,2h,2w] -> [B,C,2h,2w]."""
+    x, skip, up_w, cr_w = _chk(x, "x"), _chk(skip, "skip"), _chk(up_w, "up_w"), _chk(cr_w, "cr_w")
+    b, c2, h, w = x.shape
+    c = c2 // 2
+    if tuple(skip.shape) != (b, c, 2 * h, 2 * w) or tuple(up_w.shape) != (c2, c, 2, 2) or tuple(cr_w.shape) != (c, c2, 1, 1):
+        raise RuntimeError("upsample_cat_reduce: shapes do not describe ConvTranspose2d(2C,C,2,2) + cat + Conv2d(2C,C,1)")
+    lib = _lib.load()
+    sz = C.c_size_t()
+    _lib.check(lib.rf_upcat_scratch_bytes(c, C.byref(sz)), "rf_upcat_scratch_bytes")
+    scratch = _scratch(sz.value, x)
+    out = torch.empty_like(skip)
+    with torch.cuda.device(x.device):
+        _lib.check(lib.rf_upcat(_ptr(x), _ptr(skip), _ptr(out), _ptr(up_w), _ptr(None if up_b is None else _chk(up_b, "up_b")), _ptr(cr_w),
+                                _ptr(None if cr_b is None else _chk(cr_b, "cr_b")), _ptr(scratch), b, c, h, w, _stream(x)), "rf_upcat")
+    return out

@@ -150,6 +150,13 @@ int rf_flca(const float* feat, const float* guide, float* out, const float* cons
 int rf_guidance_scratch_bytes(int B, int H, int W, size_t* bytes);
 int rf_flca_guidance(const float* packed, float* guide, void* scratch, int B, int H, int W, int hf, int wf, void* stream);
 
+/* Decoder step of RawFormer.forward (RawFomer_WFB_FFAB/model.py:461-468, 494-503) as one kernel on composed weights:
+ *   out = Conv2d(2C, C, 1)(cat[ConvTranspose2d(2C, C, 2, stride=2)(x), skip])
+ * x [B,2C,h,w], skip and out [B,C,2h,2w]; up_w [2C,C,2,2], up_b [C], cr_w [C,2C,1,1], cr_b [C]; w % 4 == 0. */
+int rf_upcat_scratch_bytes(int C, size_t* bytes);
+int rf_upcat(const float* x, const float* skip, float* out, const float* up_w, const float* up_b, const float* cr_w, const float* cr_b,
+             void* scratch, int B, int C, int h, int w, void* stream);
+
 /* ---- evaluation harness: test.py:117-124 on the device ----------- */
 /* (clamp(pred,0,1) * 255).astype(uint8), CHW float32 -> HWC uint8 (truncation): test.py:117-118 */
 int rf_to_uint8_hwc(const float* in, unsigned char* out, int B, int C, int h, int w, void* stream);
