@@ -34,7 +34,8 @@ int gram_plan(int B, int C, int heads, int P, int* nslab, int* slab, size_t* par
     const int NTq = cdiv(C, 16);
     // the slab split depends only on (C, P), never on B: an image's result is bitwise the same
     // alone and inside a batch
-    int target = P / 64;                       // pixels per slab: at most 64 slabs per image,
+    int target = P / 16;                       // pixels per slab: at most 16 slabs per image (a slab's fixed cost -- ramp,
+                                               // LDS reduction, 1056 stores -- is worth about 600 pixels),
     if (target < 1024) target = 1024;          // at least 1024 px so small levels still fill the GPU
     if (target > 8192) target = 8192;
     int ns = cdiv(P, target);
@@ -81,29 +82,57 @@ __global__ void __launch_bounds__(256) gram_kernel(GramArgs a, int vec) {
         return v;
     };
 
-    // a wave step covers 16 pixels: lane (i, kq) holds pixels n + 4kq .. 4kq+3 of channel row i
-    for (int n = n_lo + wave * 16; n < n_hi; n += 64) {
-        const int nn = n + 4 * kq;
-        const float4 qv = load4(qb, 16 * tq + i, nn);
-        float4 kv[kMaxBand];
-#pragma unroll
-        for (int t = 0; t < kMaxBand; ++t)
-            kv[t] = (t < nb) ? load4(kb, 16 * (tklo + t) + i, nn) : make_float4(0.f, 0.f, 0.f, 0.f);
-        const float4 kd = load4(kb, 16 * tq + i, nn);   // k rows of the diagonal tile (for |k|^2)
+    // a wave step covers 16 pixels: lane (i, kq) holds pixels n + 4kq .. 4kq+3 of channel row i.
+    // The k rows of the diagonal tile (for |k|^2) are the band tile tq - tklo: no separate load.
+    const int td = tq - tklo;
+    auto mfma_step = [&](const float4& qv, const float4 (&kv)[kMaxBand]) __attribute__((always_inline)) {
         const float qa[4] = {qv.x, qv.y, qv.z, qv.w};
-        const float ka[4] = {kd.x, kd.y, kd.z, kd.w};
 #pragma unroll
-        for (int m = 0; m < 4; ++m) {
-            nq = __builtin_amdgcn_mfma_f32_16x16x4f32(qa[m], qa[m], nq, 0, 0, 0);
-            nk = __builtin_amdgcn_mfma_f32_16x16x4f32(ka[m], ka[m], nk, 0, 0, 0);
-        }
+        for (int m = 0; m < 4; ++m) nq = __builtin_amdgcn_mfma_f32_16x16x4f32(qa[m], qa[m], nq, 0, 0, 0);
 #pragma unroll
         for (int t = 0; t < kMaxBand; ++t) {
             if (t < nb) {
                 const float kt[4] = {kv[t].x, kv[t].y, kv[t].z, kv[t].w};
 #pragma unroll
                 for (int m = 0; m < 4; ++m) g[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(qa[m], kt[m], g[t], 0, 0, 0);
+                if (t == td) {
+#pragma unroll
+                    for (int m = 0; m < 4; ++m) nk = __builtin_amdgcn_mfma_f32_16x16x4f32(kt[m], kt[m], nk, 0, 0, 0);
+                }
             }
+        }
+    };
+    const bool fast = vec && 16 * tq + 16 <= C && 16 * (tklo + nb) <= C && ((n_hi - n_lo) % 64 == 0);
+    if (fast) {
+        // every load in range: branch-free, and the next step's loads are issued before this step's MFMAs
+        const float* qp = qb + (size_t)(16 * tq + i) * P + 4 * kq;
+        const float* kp = kb + (size_t)(16 * tklo + i) * P + 4 * kq;
+        auto load_step = [&](int n, float4& qv, float4 (&kv)[kMaxBand]) __attribute__((always_inline)) {
+            qv = *reinterpret_cast<const float4*>(qp + n);
+#pragma unroll
+            for (int t = 0; t < kMaxBand; ++t)
+                kv[t] = *reinterpret_cast<const float4*>(kp + (size_t)(t < nb ? t : 0) * 16 * P + n);
+        };
+        float4 q0, q1, k0[kMaxBand], k1[kMaxBand];
+        int n = n_lo + wave * 16;
+        load_step(n, q0, k0);
+        for (; n < n_hi; n += 128) {
+            const bool more1 = n + 64 < n_hi;
+            load_step(more1 ? n + 64 : n, q1, k1);
+            mfma_step(q0, k0);
+            if (!more1) break;
+            load_step(n + 128 < n_hi ? n + 128 : n, q0, k0);
+            mfma_step(q1, k1);
+        }
+    } else {
+        for (int n = n_lo + wave * 16; n < n_hi; n += 64) {
+            const int nn = n + 4 * kq;
+            const float4 qv = load4(qb, 16 * tq + i, nn);
+            float4 kv[kMaxBand];
+#pragma unroll
+            for (int t = 0; t < kMaxBand; ++t)
+                kv[t] = (t < nb) ? load4(kb, 16 * (tklo + t) + i, nn) : make_float4(0.f, 0.f, 0.f, 0.f);
+            mfma_step(qv, kv);
         }
     }
 
