@@ -540,8 +540,15 @@ int launch_conv1x1(const Conv1x1Args& a, hipStream_t st) {
             default: launch_res<32>(a, ntw, ngroups, ablate, grid, lds, st); break;
         }
     } else {
-        // accumulator tiles per workgroup: 8 (128 channels) unless that would be mostly padding
-        const int nco = (NT % 8 == 0 || NT > 12) ? 8 : 4;
+        // accumulator tiles per workgroup: 8 (128 channels) unless that would be mostly padding -- or unless the grid
+        // would fill the 512 resident workgroup slots badly (level 3 of config 2: 256 or 768 workgroups = half-empty
+        // rounds); 4 tiles per workgroup double the grid.  The k order per output is the same either way (same bits).
+        int nco = (NT % 8 == 0 || NT > 12) ? 8 : 4;
+        if (nco == 8) {
+            const long units = (long)cdiv(a.P, 256) * a.B;
+            const long cost8 = ((units * cdiv(NT, 8) + 511) / 512) * 8, cost4 = ((units * cdiv(NT, 4) + 511) / 512) * 4;
+            if (cost4 < cost8) nco = 4;
+        }
         const int ngroups = cdiv(NT, nco);
         dim3 grid((unsigned)(cdiv(a.P, 256) * ngroups), (unsigned)a.B, 1);
         snprintf(key, sizeof(key), "conv1x1_stream_kernel<%d, %d, %s>", nco, nco == 8 ? 4 : 8, a.ln_w ? "true" : "false");
