@@ -54,6 +54,8 @@ __global__ void __launch_bounds__(64 * NWV, (NWV == 8 || NCO >= 3) ? 1 : 2) conv
     constexpr int WPT = (NW4 + NTHR - 1) / NTHR;
     constexpr int BUF = KC * PS + 2 * TAPS * NCO * 64;  // floats per LDS buffer
     __shared__ __attribute__((aligned(16))) float lds[2 * BUF];
+    __shared__ float bias_l[NCO * 16];       // the epilogue must not read global memory: a load there is followed by
+                                             // s_waitcnt vmcnt(0), one exposed round trip per bias value and tile
 
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
@@ -168,6 +170,10 @@ __global__ void __launch_bounds__(64 * NWV, (NWV == 8 || NCO >= 3) ? 1 : 2) conv
     int tile = wg;
     const int tile_end = ntiles;
     if (tile >= tile_end) return;
+    if (tid < NCO * 16) {
+        const int co = 16 * t0 + tid;
+        bias_l[tid] = (a.bias && co < a.Cout) ? a.bias[co] : 0.f;
+    }
     plan_tile(tile);
     load_chunk(0);
     store_chunk(0);
@@ -242,8 +248,7 @@ __global__ void __launch_bounds__(64 * NWV, (NWV == 8 || NCO >= 3) ? 1 : 2) conv
         float v[4][4];   // [r][g]
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-            const int co = 16 * (t0 + t) + 4 * kq_ + r;
-            const float bs = (a.bias && co < a.Cout) ? a.bias[co] : 0.f;
+            const float bs = bias_l[16 * t + 4 * kq_ + r];
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
                 // output transform A^T m of the lane's F(4,3) tile

@@ -39,8 +39,10 @@ namespace rf {
 // wave-uniform base of the 4-channel k-set s (channels 4s .. 4s+3 come from one source)
 __device__ __forceinline__ const float* kset_base(const Conv1x1Args& a, int b, int s) {
     const int k = 4 * s;
-    return (k < a.C1) ? a.x1 + (size_t)b * a.x1_bstride + (size_t)k * a.P
-                      : a.x2 + (size_t)b * a.x2_bstride + (size_t)(k - a.C1) * a.P;
+    const bool first = k < a.C1;                       // selects, not branches: a branch around the loads that use this
+    const float* src = first ? a.x1 : a.x2;            // base makes hipcc close each block with s_waitcnt vmcnt(0)
+    const size_t off = (size_t)b * (size_t)(first ? a.x1_bstride : a.x2_bstride) + (size_t)(first ? k : k - a.C1) * (size_t)a.P;
+    return src + off;
 }
 
 __device__ __forceinline__ float4 ldv(const float* __restrict__ base, unsigned off) {
@@ -325,18 +327,20 @@ __global__ void __launch_bounds__(256, 2) conv1x1_stream_kernel(Conv1x1Args a, i
     for (int t = 0; t < NCO; ++t)
 #pragma unroll
         for (int g = 0; g < 4; ++g) acc[t][g] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    if (a.res && a.mode == 0 && live) {
+    if (a.res && a.mode == 0) {   // (wave-uniform)
+        // branch-free: a conditional block around each load would be closed with s_waitcnt vmcnt(0), i.e. 32
+        // serialised round trips to HBM; rows that do not exist read row 0 of the image and are masked to zero
         const float* resb = a.res + (size_t)b * a.res_bstride;
-        const unsigned vo = (unsigned)(4 * kq) * (unsigned)P + (unsigned)p0;
+        const unsigned vo = (unsigned)(live ? p0 : 0);
 #pragma unroll
         for (int t = 0; t < NCO; ++t)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const int cu = 16 * (t0 + t) + r;
-                if (t < tcnt && cu + 4 * kq < a.Cout) {
-                    const float4 rv = ldv(resb + (size_t)cu * P, vo);
-                    acc[t][0][r] = rv.x; acc[t][1][r] = rv.y; acc[t][2][r] = rv.z; acc[t][3][r] = rv.w;
-                }
+                const int co = 16 * (t0 + t) + 4 * kq + r;
+                const bool ok = live && t < tcnt && co < a.Cout;
+                const float4 rv = ldv(resb + (size_t)(ok ? co : 0) * P, vo);
+                acc[t][0][r] = ok ? rv.x : 0.f; acc[t][1][r] = ok ? rv.y : 0.f;
+                acc[t][2][r] = ok ? rv.z : 0.f; acc[t][3][r] = ok ? rv.w : 0.f;
             }
     }
 
@@ -395,6 +399,11 @@ __global__ void __launch_bounds__(256, 2) conv1x1_stream_kernel(Conv1x1Args a, i
             load_w_chunk(c + 1);
         }
         const float* wl = &lds_w[c & 1][lane];
+        // A operands one k-set ahead of the MFMAs that use them (the LDS latency of a k-set hides behind the 4 NCO
+        // MFMAs of the previous one instead of being waited for in front of every group of 4)
+        float an[NCO];
+#pragma unroll
+        for (int t = 0; t < NCO; ++t) an[t] = wl[t * 64];
 #pragma unroll
         for (int i = 0; i < KCH; ++i) {
             float xv[4] = {xc[i].x, xc[i].y, xc[i].z, xc[i].w};
@@ -404,12 +413,18 @@ __global__ void __launch_bounds__(256, 2) conv1x1_stream_kernel(Conv1x1Args a, i
 #pragma unroll
                 for (int g = 0; g < 4; ++g) xv[g] = fmaf(fmaf(xv[g], lnA[g], lnB[g]), gk, bk);
             }
+            float av[NCO];
+#pragma unroll
+            for (int t = 0; t < NCO; ++t) av[t] = an[t];
+            if (i + 1 < KCH) {
+#pragma unroll
+                for (int t = 0; t < NCO; ++t) an[t] = wl[((i + 1) * NCO + t) * 64];
+            }
 #pragma unroll
             for (int t = 0; t < NCO; ++t) {
-                const float av = wl[(i * NCO + t) * 64];
 #pragma unroll
                 for (int g = 0; g < 4; ++g)
-                    acc[t][g] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, xv[g], acc[t][g], 0, 0, 0);
+                    acc[t][g] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[t], xv[g], acc[t][g], 0, 0, 0);
             }
         }
         if (c + 1 < nch) store_w_chunk((c + 1) & 1);

@@ -352,21 +352,16 @@ __global__ void __launch_bounds__(kBlock) dwconv3x3_kernel(DwConvArgs a) {
             const int y = y0 + rr - 1;
             float v[VEC + 2];
             if constexpr (VEC == 4) {
-                // Row segment as one 16-byte load; the two edge taps come from the neighbouring
-                // lanes (wave shuffle) -- consecutive lanes hold consecutive 4-pixel groups of the
-                // same row, and where they do not (row ends) the tap is zero padding anyway.  Only
-                // the first / last lane of a wave fetch their outer tap from memory.
+                // Row segment as one 16-byte load plus the two edge taps, all three UNCONDITIONAL (clamped
+                // addresses, values masked afterwards): a load inside a conditional block is followed by
+                // s_waitcnt vmcnt(0), which serialised the 10 rows of a thread into 10 round trips.
                 const bool rok = y >= 0 && y < h;
                 const float* row = x + (size_t)(rok ? y : 0) * w;
-                float4 t = *reinterpret_cast<const float4*>(row + x0);
-                if (!rok) t = make_float4(0.f, 0.f, 0.f, 0.f);
-                v[1] = t.x; v[2] = t.y; v[3] = t.z; v[4] = t.w;
-                float l = __shfl_up(t.w, 1), r = __shfl_down(t.x, 1);
-                const int lane = threadIdx.x & 63;
-                if (lane == 0) l = (rok && x0 > 0) ? row[x0 - 1] : 0.f;
-                if (lane == 63) r = (rok && x0 + 4 < w) ? row[x0 + 4] : 0.f;
-                v[0] = x0 > 0 ? l : 0.f;
-                v[5] = x0 + 4 < w ? r : 0.f;
+                const float4 t = *reinterpret_cast<const float4*>(row + x0);
+                const float l = row[x0 > 0 ? x0 - 1 : 0], r = row[x0 + 4 < w ? x0 + 4 : x0];
+                v[1] = rok ? t.x : 0.f; v[2] = rok ? t.y : 0.f; v[3] = rok ? t.z : 0.f; v[4] = rok ? t.w : 0.f;
+                v[0] = (rok && x0 > 0) ? l : 0.f;
+                v[5] = (rok && x0 + 4 < w) ? r : 0.f;
             } else if (y >= 0 && y < h) {
                 const float* row = x + (size_t)y * w;
                 v[1] = row[x0];
