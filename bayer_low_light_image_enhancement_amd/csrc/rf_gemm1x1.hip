@@ -399,11 +399,6 @@ __global__ void __launch_bounds__(256, 2) conv1x1_stream_kernel(Conv1x1Args a, i
             load_w_chunk(c + 1);
         }
         const float* wl = &lds_w[c & 1][lane];
-        // A operands one k-set ahead of the MFMAs that use them (the LDS latency of a k-set hides behind the 4 NCO
-        // MFMAs of the previous one instead of being waited for in front of every group of 4)
-        float an[NCO];
-#pragma unroll
-        for (int t = 0; t < NCO; ++t) an[t] = wl[t * 64];
 #pragma unroll
         for (int i = 0; i < KCH; ++i) {
             float xv[4] = {xc[i].x, xc[i].y, xc[i].z, xc[i].w};
@@ -413,18 +408,14 @@ __global__ void __launch_bounds__(256, 2) conv1x1_stream_kernel(Conv1x1Args a, i
 #pragma unroll
                 for (int g = 0; g < 4; ++g) xv[g] = fmaf(fmaf(xv[g], lnA[g], lnB[g]), gk, bk);
             }
-            float av[NCO];
-#pragma unroll
-            for (int t = 0; t < NCO; ++t) av[t] = an[t];
-            if (i + 1 < KCH) {
-#pragma unroll
-                for (int t = 0; t < NCO; ++t) an[t] = wl[((i + 1) * NCO + t) * 64];
-            }
+            // (reading the A operands one k-set ahead, pinned with sched_barrier, was measured: no gain -- the LDS
+            // latency is already covered by the other wave of the SIMD)
 #pragma unroll
             for (int t = 0; t < NCO; ++t) {
+                const float av = wl[(i * NCO + t) * 64];
 #pragma unroll
                 for (int g = 0; g < 4; ++g)
-                    acc[t][g] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[t], xv[g], acc[t][g], 0, 0, 0);
+                    acc[t][g] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, xv[g], acc[t][g], 0, 0, 0);
             }
         }
         if (c + 1 < nch) store_w_chunk((c + 1) & 1);
