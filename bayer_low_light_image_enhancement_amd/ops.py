@@ -459,3 +459,23 @@ def upsample_cat_reduce(x: torch.Tensor, skip: torch.Tensor, up_w: torch.Tensor,
         _lib.check(lib.rf_upcat(_ptr(x), _ptr(skip), _ptr(out), _ptr(up_w), _ptr(None if up_b is None else _chk(up_b, "up_b")), _ptr(cr_w),
                                 _ptr(None if cr_b is None else _chk(cr_b, "cr_b")), _ptr(scratch), b, c, h, w, _stream(x)), "rf_upcat")
     return out
+
+
+def atten_transformer_block(x: torch.Tensor, luma: torch.Tensor, params, heads: int = 8, prefix: str = "") -> torch.Tensor:
+    """``Attenblock.TransformerBlock.forward(x, luma=luma)`` (Attenblock.py:225-236): ``x + attn(LN1(x))`` then
+    ``x + ffn(LN2(x))`` with ``LuminanceAwareMHSA`` and ``ConvFFN``.  Both LayerNorms ride in the prologue of the 1x1
+    GEMM that consumes them, both residuals in the epilogue of the 1x1 GEMM that produces the branch."""
+    p = lambda k: params.get(prefix + k)  # noqa: E731
+    a = prefix + "attn."
+    qkv = conv1x1(x, params[a + "to_qkv.weight"], params.get(a + "to_qkv.bias"), ln_weight=p("norm1.body.weight"), ln_bias=p("norm1.body.bias"))
+    hcond = conv3x3(luma, params[a + "luma_cond.net.0.weight"], params[a + "luma_cond.net.0.bias"], act="relu")
+    hcond = conv3x3(hcond, params[a + "luma_cond.net.2.weight"], params[a + "luma_cond.net.2.bias"], act="relu")
+    gamma = conv1x1(hcond, params[a + "luma_cond.gamma.weight"], params[a + "luma_cond.gamma.bias"])
+    beta = conv1x1(hcond, params[a + "luma_cond.beta.weight"], params[a + "luma_cond.beta.bias"])
+    alpha = params.get(a + "alpha")
+    qkv = luma_film(qkv, gamma, beta, luma if alpha is not None else None, None if alpha is None else alpha.reshape(1))
+    x1 = conv1x1(token_attention(qkv, heads), params[a + "proj.weight"], params.get(a + "proj.bias"), residual=x)
+    f = prefix + "ffn."
+    hid = conv1x1(x1, params[f + "pointwise1.weight"], params.get(f + "pointwise1.bias"), ln_weight=p("norm2.body.weight"), ln_bias=p("norm2.body.bias"))
+    hid = dwconv3x3(hid, params[f + "depthwise.weight"], params.get(f + "depthwise.bias"), gelu=True)
+    return conv1x1(hid, params[f + "pointwise2.weight"], params.get(f + "pointwise2.bias"), residual=x1)

@@ -372,6 +372,17 @@ def attenblock():
         assert maxabs(y, mine) < 2e-5
         out[f"{tag}.out"] = y
         out[f"{tag}.checksum_x"] = checksum(x)
+    # the whole Attenblock.TransformerBlock (LayerNorm, LuminanceAwareMHSA, ConvFFN, two residuals)
+    for tag, dim, heads, b, h, w in ATTEN_CASES[:2]:
+        m = fill(ab.TransformerBlock(dim, heads, 2), 750 + dim)
+        x = rnd(43, f"atten.tb.{tag}.x", (b, dim, h, w))
+        luma = rnd(44, f"atten.tb.{tag}.luma", (b, 1, h, w), 0.0, 1.0)
+        with torch.no_grad():
+            y = m(x, luma=luma)
+            mine = R.atten_transformer_block(x, luma, sd_of(m), "", heads)
+        log(f"  Attenblock.TransformerBlock {tag} dim={dim} heads={heads} {b}x{h}x{w}: oracle vs reference {maxabs(y, mine):.2e}")
+        assert maxabs(y, mine) < 2e-5
+        out[f"tb.{tag}.out"] = y
     save("attenblock", **out)
 
 

@@ -452,3 +452,12 @@ def illumination_estimator(img: Tensor, p: Dict[str, Tensor], pre: str) -> Tuple
     x1 = F.conv2d(inp, p[pre + "conv1.weight"], p[pre + "conv1.bias"])
     fea = F.conv2d(x1, p[pre + "depth_conv.weight"], p[pre + "depth_conv.bias"], padding=2, groups=x1.shape[1])
     return fea, F.conv2d(fea, p[pre + "conv2.weight"], p[pre + "conv2.bias"])
+
+
+def atten_transformer_block(x: Tensor, luma: Tensor, p: Dict[str, Tensor], pre: str, heads: int) -> Tensor:
+    """Attenblock.TransformerBlock.forward(x, luma=luma) (Attenblock.py:225-236); LayerNorm = nn.LayerNorm over channels
+    (Attenblock.py:37-45), ConvFFN = 1x1 -> dw3x3 -> GELU -> 1x1 (Attenblock.py:47-66)."""
+    x = x + luminance_aware_mhsa(layernorm2d(x, p[pre + "norm1.body.weight"], p[pre + "norm1.body.bias"]), luma, p, pre + "attn.", heads)
+    y = layernorm2d(x, p[pre + "norm2.body.weight"], p[pre + "norm2.body.bias"])
+    return x + conv_ffn(y, p[pre + "ffn.pointwise1.weight"], p[pre + "ffn.pointwise1.bias"], p[pre + "ffn.depthwise.weight"],
+                        p[pre + "ffn.depthwise.bias"], p[pre + "ffn.pointwise2.weight"], p[pre + "ffn.pointwise2.bias"])

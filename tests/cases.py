@@ -127,3 +127,16 @@ def wfb_ff_spec(dim, fac):
 def wfb_ie_spec(mid):
     return {"conv1.weight": (mid, 4, 1, 1), "conv1.bias": (mid,), "depth_conv.weight": (mid, 1, 5, 5), "depth_conv.bias": (mid,),
             "conv2.weight": (3, mid, 1, 1), "conv2.bias": (3,)}
+
+
+def atten_tb_spec(dim, heads):
+    s = {"norm1.body.weight": (dim,), "norm1.body.bias": (dim,), "norm2.body.weight": (dim,), "norm2.body.bias": (dim,)}
+    s.update({"attn." + k: v for k, v in atten_spec(dim, heads).items()})
+    s.update({"ffn." + k: v for k, v in ffn_spec(dim).items()})
+    return s
+
+
+def atten_tb_inputs(tag, dim, heads, b, h, w):
+    x = rnd(f"atten.tb.{tag}.x", (b, dim, h, w), seed=43)
+    luma = rnd(f"atten.tb.{tag}.luma", (b, 1, h, w), 0.0, 1.0, seed=44)
+    return x, luma, params(atten_tb_spec(dim, heads), seed=750 + dim)
