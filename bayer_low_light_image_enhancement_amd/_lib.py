@@ -67,6 +67,8 @@ SIGNATURES = {
     "rf_u8_channel_sums": (_i, [_vp, _vp, _i, _i, _sz, _vp]),
     "rf_sid_pack": (_i, [_vp, _vp, _i, _i, _i, _i, _i, C.c_double, _i, _vp]),
     "rf_token_attn": (_i, [_vp, _vp, _vp, _vp, C.c_longlong, C.c_longlong, _i, _i, _i, _i, _f, _vp]),
+    "rf_bayer_luma_scratch_bytes": (_i, [_i, _i, _i, _psz]),
+    "rf_bayer_luma": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _vp]),
     "rf_luma_film_scratch_bytes": (_i, [_i, _i, _i, _psz]),
     "rf_luma_film": (_i, [_vp, _vp, _vp, C.c_longlong, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
     "rf_dwgate3x3": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),

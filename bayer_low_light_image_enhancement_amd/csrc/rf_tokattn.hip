@@ -209,6 +209,60 @@ __global__ void __launch_bounds__(256) luma_film_kernel(const float* __restrict_
     }
 }
 
+// ---- BayerLuma (Attenblock.py:79-138): the three 3x3 "mask" convolutions pick neighbours of the mosaic
+//   rggb: r = in[y-1][x-1], g = (in[y-1][x] + in[y][x-1]) / 2, b = in[y][x]      (zero padded; other patterns permute)
+// luma = .299 r + .587 g + .114 b, then (luma - min) / (max - min + 1e-6) per image.  Pass 1 writes luma and per-block
+// min / max, pass 2 reduces them (min / max are order independent) and normalises.
+__device__ __forceinline__ float nofma(float v) { asm volatile("" : "+v"(v)); return v; }   // keeps a product from contracting
+
+__global__ void __launch_bounds__(256) bayer_luma_kernel(const float* __restrict__ in, float* __restrict__ luma,
+                                                         float* __restrict__ pmin, float* __restrict__ pmax, int H, int W, int pattern, int nblk) {
+    const size_t b = blockIdx.y;
+    const int P = H * W;
+    const float* ib = in + b * P;
+    const int p = blockIdx.x * 256 + threadIdx.x;
+    float v = 0.f, lo = INFINITY, hi = -INFINITY;
+    if (p < P) {
+        const int y = p / W, x = p - y * W;
+        const float c = ib[p];
+        const float u = y > 0 ? ib[p - W] : 0.f, l = x > 0 ? ib[p - 1] : 0.f, ul = (y > 0 && x > 0) ? ib[p - W - 1] : 0.f;
+        // tap (0,0) = ul, (0,1) = u, (1,0) = l, (1,1) = c
+        float r, g, bl;
+        if (pattern == 0) { r = ul; g = nofma(0.5f * u) + nofma(0.5f * l); bl = c; }          // rggb
+        else if (pattern == 1) { bl = ul; g = nofma(0.5f * u) + nofma(0.5f * l); r = c; }     // bggr
+        else if (pattern == 2) { g = nofma(0.5f * ul) + nofma(0.5f * c); r = u; bl = l; }     // grbg
+        else { g = nofma(0.5f * ul) + nofma(0.5f * c); bl = u; r = l; }                       // gbrg
+        v = (nofma(r * 0.299f) + nofma(g * 0.587f)) + nofma(bl * 0.114f);
+        luma[b * P + p] = v;
+        lo = hi = v;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { lo = fminf(lo, __shfl_xor(lo, o)); hi = fmaxf(hi, __shfl_xor(hi, o)); }
+    __shared__ float rl[4], rh[4];
+    if ((threadIdx.x & 63) == 0) { rl[threadIdx.x >> 6] = lo; rh[threadIdx.x >> 6] = hi; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        pmin[b * nblk + blockIdx.x] = fminf(fminf(rl[0], rl[1]), fminf(rl[2], rl[3]));
+        pmax[b * nblk + blockIdx.x] = fmaxf(fmaxf(rh[0], rh[1]), fmaxf(rh[2], rh[3]));
+    }
+}
+
+__global__ void __launch_bounds__(256) bayer_luma_norm_kernel(float* __restrict__ luma, const float* __restrict__ pmin,
+                                                              const float* __restrict__ pmax, int P, int nblk) {
+    const size_t b = blockIdx.y;
+    __shared__ float rl[256], rh[256];
+    float lo = INFINITY, hi = -INFINITY;
+    for (int i = threadIdx.x; i < nblk; i += 256) { lo = fminf(lo, pmin[b * nblk + i]); hi = fmaxf(hi, pmax[b * nblk + i]); }
+    rl[threadIdx.x] = lo; rh[threadIdx.x] = hi;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if ((int)threadIdx.x < o) { rl[threadIdx.x] = fminf(rl[threadIdx.x], rl[threadIdx.x + o]); rh[threadIdx.x] = fmaxf(rh[threadIdx.x], rh[threadIdx.x + o]); }
+        __syncthreads();
+    }
+    const float mn = rl[0], den = (rh[0] - rl[0]) + 1e-6f;
+    for (int p = blockIdx.x * 256 + threadIdx.x; p < P; p += gridDim.x * 256) luma[b * P + p] = (luma[b * P + p] - mn) / den;
+}
+
 }  // namespace rf
 
 using namespace rf;
@@ -260,4 +314,23 @@ int rf_luma_film(const float* qkv, const float* gamma, const float* beta, long l
     return check_launch("luma_film");
 }
 
+int rf_bayer_luma_scratch_bytes(int B, int H, int W, size_t* bytes) {
+    RF_CHECK_ARG(bytes && B > 0 && H > 0 && W > 0, "bayer_luma_scratch_bytes: bad arguments");
+    *bytes = sizeof(float) * 2 * align_up((size_t)B * cdiv(H * W, 256), 64);
+    return RF_OK;
+}
+
+int rf_bayer_luma(const float* mosaic, float* luma, void* scratch, int B, int H, int W, int pattern, void* stream) {
+    RF_CHECK_ARG(mosaic && luma && scratch && B > 0 && B <= 65535 && H > 0 && W > 0, "bayer_luma: bad arguments");
+    RF_CHECK_ARG(pattern >= 0 && pattern <= 3, "bayer_luma: pattern %d (0 rggb, 1 bggr, 2 grbg, 3 gbrg)", pattern);
+    hipStream_t st = (hipStream_t)stream;
+    const int P = H * W, nblk = cdiv(P, 256);
+    float* pmin = static_cast<float*>(scratch);
+    float* pmax = pmin + align_up((size_t)B * nblk, 64);
+    ProfScope prof(st, "bayer_luma(2 kernels)", 0.0, 16.0 * B * P);
+    bayer_luma_kernel<<<dim3((unsigned)nblk, (unsigned)B), 256, 0, st>>>(mosaic, luma, pmin, pmax, H, W, pattern, nblk);
+    int gx = nblk > 1024 ? 1024 : nblk;
+    bayer_luma_norm_kernel<<<dim3((unsigned)gx, (unsigned)B), 256, 0, st>>>(luma, pmin, pmax, P, nblk);
+    return check_launch("bayer_luma");
+}
 }  // extern "C"

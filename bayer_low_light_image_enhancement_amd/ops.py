@@ -479,3 +479,20 @@ def atten_transformer_block(x: torch.Tensor, luma: torch.Tensor, params, heads: 
     hid = conv1x1(x1, params[f + "pointwise1.weight"], params.get(f + "pointwise1.bias"), ln_weight=p("norm2.body.weight"), ln_bias=p("norm2.body.bias"))
     hid = dwconv3x3(hid, params[f + "depthwise.weight"], params.get(f + "depthwise.bias"), gelu=True)
     return conv1x1(hid, params[f + "pointwise2.weight"], params.get(f + "pointwise2.bias"), residual=x1)
+
+
+def bayer_luma(mosaic: torch.Tensor, pattern: str = "rggb") -> torch.Tensor:
+    """``BayerLuma(pattern)(mosaic)`` (Attenblock.py:79-138): ``[B,1,H,W]`` mosaic -> normalised luma ``[B,1,H,W]``."""
+    mosaic = _chk(mosaic, "mosaic")
+    b, c, h, w = mosaic.shape
+    if c != 1:
+        raise RuntimeError("bayer_luma expects a one-channel mosaic")
+    pat = {"rggb": 0, "bggr": 1, "grbg": 2, "gbrg": 3}[pattern.lower()]
+    lib = _lib.load()
+    sz = C.c_size_t()
+    _lib.check(lib.rf_bayer_luma_scratch_bytes(b, h, w, C.byref(sz)), "rf_bayer_luma_scratch_bytes")
+    scratch = _scratch(sz.value, mosaic)
+    out = torch.empty_like(mosaic)
+    with torch.cuda.device(mosaic.device):
+        _lib.check(lib.rf_bayer_luma(_ptr(mosaic), _ptr(out), _ptr(scratch), b, h, w, pat, _stream(mosaic)), "rf_bayer_luma")
+    return out

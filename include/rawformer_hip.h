@@ -180,6 +180,10 @@ int rf_sid_pack(const unsigned short* raw, float* out, int B, int h, int w, int 
  * [B, 3*heads*d, N] tensor); out: [B, heads*d, N].  Einsums of Attenblock.py:212-216.  d <= 32. */
 int rf_token_attn(const float* q, const float* k, const float* v, float* out, long long bstride_qkv, long long bstride_out,
                   int B, int heads, int d, int N, float scale, void* stream);
+/* BayerLuma (Attenblock.py:79-138): mosaic [B,1,H,W] -> luma [B,1,H,W] in [0,1]: the 3x3 mask convolutions of the
+ * pattern (0 rggb, 1 bggr, 2 grbg, 3 gbrg), .299 r + .587 g + .114 b, per-image (x - min) / (max - min + 1e-6). */
+int rf_bayer_luma_scratch_bytes(int B, int H, int W, size_t* bytes);
+int rf_bayer_luma(const float* mosaic, float* luma, void* scratch, int B, int H, int W, int pattern, void* stream);
 /* FiLM of q,k,v and the query luma bias (Attenblock.py:193-210): out = gamma * qkv + beta on each third of
  * qkv [B, 3*inner, h*w]; the q third also gets alpha * (avg_pool3(1 - luma) - mean) when luma [B,1,h,w] != NULL.
  * gamma, beta: [B, inner, h*w] with `gb_bstride` floats between images; alpha: device scalar. */

@@ -383,6 +383,14 @@ def attenblock():
         log(f"  Attenblock.TransformerBlock {tag} dim={dim} heads={heads} {b}x{h}x{w}: oracle vs reference {maxabs(y, mine):.2e}")
         assert maxabs(y, mine) < 2e-5
         out[f"tb.{tag}.out"] = y
+    for pat in ("rggb", "bggr", "grbg", "gbrg"):
+        mos = rnd(45, "atten.mosaic", (2, 1, 18, 22), 0.0, 1.0)
+        with torch.no_grad():
+            y = ab.BayerLuma(pat)(mos)
+        mine = R.bayer_luma(mos, pat)
+        log(f"  BayerLuma {pat}: oracle vs reference {maxabs(y, mine):.2e}")
+        assert maxabs(y, mine) < 1e-6
+        out[f"luma.{pat}"] = y
     save("attenblock", **out)
 
 

@@ -461,3 +461,15 @@ def atten_transformer_block(x: Tensor, luma: Tensor, p: Dict[str, Tensor], pre: 
     y = layernorm2d(x, p[pre + "norm2.body.weight"], p[pre + "norm2.body.bias"])
     return x + conv_ffn(y, p[pre + "ffn.pointwise1.weight"], p[pre + "ffn.pointwise1.bias"], p[pre + "ffn.depthwise.weight"],
                         p[pre + "ffn.depthwise.bias"], p[pre + "ffn.pointwise2.weight"], p[pre + "ffn.pointwise2.bias"])
+
+
+def bayer_luma(mosaic: Tensor, pattern: str = "rggb") -> Tensor:
+    """BayerLuma.forward (Attenblock.py:127-138) with the mask kernels of ``_create_kernel`` (:92-125)."""
+    k = {c: torch.zeros(1, 1, 3, 3) for c in "rgb"}
+    pos = {"rggb": ("r", "g", "g", "b"), "bggr": ("b", "g", "g", "r"), "grbg": ("g", "r", "b", "g"), "gbrg": ("g", "b", "r", "g")}[pattern.lower()]
+    for (i, j), c in zip(((0, 0), (0, 1), (1, 0), (1, 1)), pos):
+        k[c][0, 0, i, j] = 0.5 if c == "g" else 1.0
+    rgb = torch.cat([F.conv2d(mosaic, k[c], padding=1) for c in "rgb"], dim=1)
+    luma = torch.sum(rgb * torch.tensor([0.299, 0.587, 0.114]).view(1, 3, 1, 1), dim=1, keepdim=True)
+    lo, hi = luma.amin(dim=(2, 3), keepdim=True), luma.amax(dim=(2, 3), keepdim=True)
+    return (luma - lo) / (hi - lo + 1e-6)
