@@ -32,16 +32,21 @@ struct ProfScope {
     int rec_;
 };
 
-// GELU(v) = v/2 (1 + erf(v/sqrt 2)) with erf by Abramowitz-Stegun 7.1.26 (|error| <= 1.5e-7): one v_exp, one v_rcp, 6 fma
+// GELU(v) = v/2 (1 + erf(v/sqrt 2)) with erf by Abramowitz-Stegun 7.1.26 (|error| <= 1.5e-7), arranged for the fewest
+// VALU operations (this sits next to MFMAs, and f32 VALU time adds to f32 MFMA time): with h = v/2 and
+// q = 1 - erf(|v|/sqrt 2) = poly(t) t exp(-v^2/2), t = 1 / (1 + p |v|/sqrt 2):
+//   GELU = h + |h| (1 - q) = h + fma(-|h|, q, |h|)            (no sign transfer: h sign(v) = |h|)
+// 11 plain operations + v_rcp_f32 + v_exp_f32.
 __device__ __forceinline__ float gelu_fast(float v) {
-    const float x = fabsf(v) * 0.70710678118654752440f;
-    const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, x, 1.0f));
+    const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f * 0.70710678118654752440f, fabsf(v), 1.0f));
     float p = fmaf(1.061405429f, t, -1.453152027f);
     p = fmaf(p, t, 1.421413741f);
     p = fmaf(p, t, -0.284496736f);
     p = fmaf(p, t, 0.254829592f);
-    const float e = 1.0f - p * t * __expf(-x * x);       // erf(|v| / sqrt 2)
-    return 0.5f * v * (1.0f + copysignf(e, v));
+    const float ex = __builtin_amdgcn_exp2f((v * v) * (-0.5f * 1.44269504088896340736f));   // exp(-v^2 / 2)
+    const float q = (p * t) * ex;
+    const float h = 0.5f * v;
+    return h + fmaf(-fabsf(h), q, fabsf(h));
 }
 
 static inline int cdiv(int a, int b) { return (a + b - 1) / b; }
