@@ -27,6 +27,7 @@
 // input/output clamps, bias, LeakyReLU(0.2), and the pixel-unshuffle (Downsample, a8) or
 // pixel-shuffle (conv_out + PixelShuffle, a10) store.
 #include <cstdio>
+#include <cstdlib>
 #include "rf_common.h"
 
 namespace rf {
@@ -37,7 +38,7 @@ typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 // NWV = waves per workgroup: 8 on wide images (the 18-tap weight slice is shared by twice the waves, so that two
 // waves per SIMD fit the 160 KB of LDS with one workgroup per CU), 4 for the narrow-image tile shapes.
 template <int NCO, int LOG2_RW, int RPW, int NWV>
-__global__ void __launch_bounds__(64 * NWV, (NWV == 8 || NCO >= 3) ? 1 : 2) conv3x3_kernel(Conv3x3Args a, int ngroups, int tiles_x, int ntiles, int vec) {
+__global__ void __launch_bounds__(64 * NWV, (NWV >= 8 || NCO >= 3) ? 1 : 2) conv3x3_kernel(Conv3x3Args a, int ngroups, int tiles_x, int ntiles, int vec) {
     constexpr int NTHR = 64 * NWV;
     constexpr int TAPS = 18;                 // transformed taps per k-set (3 kernel rows x 6)
     constexpr int NM = 6;                    // Winograd products per lane and output tile
@@ -334,7 +335,12 @@ static void launch_rw(const Conv3x3Args& a, int ngroups, int vec, hipStream_t st
         const int wgs = cdiv(ntiles, (int)((total + 255) / 256));      // one resident workgroup per CU
         return dim3((unsigned)(ngroups * wgs), (unsigned)a.B);
     };
-    if (lrw == 0 && a.h >= 8 * RPWB) {
+    if (NCO == 1 && lrw == 0 && a.h >= 16) {
+        // one output tile: 16 waves of one row each (103 registers, four waves per SIMD cover each other's LDS and
+        // barrier waits) beat 8 waves of two rows by 7 %; with NCO = 2 the same shape spills at the 128-register cap
+        const int txs = cdiv(a.w, 64), ntiles = txs * cdiv(a.h, 16);
+        conv3x3_kernel<1, 0, 1, 16><<<grid_for_tiles(ntiles), 1024, 0, st>>>(a, ngroups, txs, ntiles, vec);
+    } else if (lrw == 0 && a.h >= 8 * RPWB) {
         const int txs = cdiv(a.w, 64), ntiles = txs * cdiv(a.h, 8 * RPWB);
         conv3x3_kernel<NCO, 0, RPWB, 8><<<grid_for_tiles(ntiles), 512, 0, st>>>(a, ngroups, txs, ntiles, vec);
     } else if (lrw == 0 && a.h >= 8) {
@@ -365,6 +371,7 @@ int launch_conv3x3(const Conv3x3Args& a, hipStream_t st) {
         const int lrw = a.w > 32 ? 0 : (a.w > 16 ? 1 : 2), rpwb = nco <= 2 ? 2 : 1;
         const int wide = lrw == 0 && a.h >= 8;
         snprintf(key, sizeof(key), "conv3x3_kernel<%d, %d, %d, %d>", nco, lrw, (wide && a.h >= 8 * rpwb) ? rpwb : 1, wide ? 8 : 4);
+        if (nco == 1 && lrw == 0 && a.h >= 16) snprintf(key, sizeof(key), "conv3x3_kernel<1, 0, 1, 16>");
     }
     const double px = (double)a.B * a.h * a.w;
     ProfScope prof(st, key, 18.0 * a.Cin * a.Cout * px, 4.0 * px * (a.Cin + a.Cout));
