@@ -204,7 +204,16 @@ __global__ void __launch_bounds__(256) attn_fold_kernel(const float* __restrict_
                 col = kMaxBand * 16 + 1;
             }
             const float* src = pb + ((size_t)(qch >> 4) * 16 + (qch & 15)) * kRowW + col;
-            for (int sl = rs; sl < nslab; sl += RS) s += src[(size_t)sl * NT * 16 * kRowW];
+            // loads of 8 slabs in flight, summed in slab order (same result, one exposed round trip per 8 instead of per slab)
+            int sl = rs;
+            for (; sl + 7 * RS < nslab; sl += 8 * RS) {
+                float t[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) t[u] = src[(size_t)(sl + u * RS) * NT * 16 * kRowW];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) s += t[u];
+            }
+            for (; sl < nslab; sl += RS) s += src[(size_t)sl * NT * 16 * kRowW];
         }
         sub[threadIdx.x] = s;
         __syncthreads();

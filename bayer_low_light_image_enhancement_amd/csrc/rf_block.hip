@@ -24,6 +24,7 @@ size_t transformer_scratch_floats(int B, int C, int heads, int hc, int h, int w,
     size_t pf = 0, pf2 = 0;
     gram_plan(B, C, heads, (int)P, &ns, &sl, &pf);
     if (fused_attn_supported(C, heads, h, w)) fused_attn_plan(h, w, &ns, &pf2, B, C);
+    if (attn_mid_supported(C, heads, h, w)) attn_mid_plan(h, w, &ns, &pf2, B, C);
     o->partial = take(pf > pf2 ? pf : pf2);
     o->wfold = take((size_t)B * packed1x1_floats(C, C));
     return off;
@@ -56,6 +57,13 @@ int run_transformer(const TbParams& p, const float* in, float* out, float* ws, c
         q.out = bufA; q.out_bstride = (int64_t)3 * C * Pn; q.Cout = 3 * C; q.B = B; q.P = Pn; q.w = ww;
         RF_TRY(launch_conv1x1(q, st));
 
+        if (!no_fuse && attn_mid_supported(C, heads, hh, ww)) {
+            // depthwise 3x3 of q, k, v + Gram partials in one kernel: dw(q), dw(k) never reach HBM
+            size_t pf;
+            RF_TRY(attn_mid_plan(hh, ww, &nslab, &pf, B, C));
+            RF_TRY(launch_attn_mid(bufA, bufB, partial, nslab, p.qkv_dw_w, p.qkv_dw_b, B, C, hh, ww, st));
+            av.x1 = bufB; av.x1_bstride = (int64_t)C * Pn;
+        } else {
         DwConvArgs d{};
         d.x = bufA; d.x_bstride = (int64_t)3 * C * Pn; d.out = bufB; d.out_bstride = (int64_t)3 * C * Pn;
         d.w = p.qkv_dw_w; d.bias = p.qkv_dw_b;
@@ -70,6 +78,7 @@ int run_transformer(const TbParams& p, const float* in, float* out, float* ws, c
         RF_TRY(launch_gram(g, st));
         nslab = g.nslab;
         av.x1 = bufB + (size_t)2 * C * Pn; av.x1_bstride = (int64_t)3 * C * Pn;
+        }
     }
     RF_TRY(launch_attn_fold(partial, nslab, p.temperature, p.proj_w, wfold, B, C, heads, st));
     av.C1 = C;

@@ -538,6 +538,202 @@ int launch_attn_front(const float* x, float* v, float* partial, int nslab, const
     return check_launch("attn_front");
 }
 
+// ================================================================================================
+// Attention middle for levels where the qkv 1x1 stays a separate GEMM (C = 64, 128):
+//   qkv [B,3C,h,w] (HBM) -> depthwise 3x3 -> { Gram partials of (q, k) per head ; v -> HBM }
+// i.e. attn_front_kernel with phase A replaced by staging halo'd qkv tiles from HBM: the depthwise-convolved
+// q and k never exist in memory (un-fused: dwconv writes 3C and the Gram kernel reads 2C of it back).
+// Round r stages q tile r (planes 0-15) and k tile r (planes 16-31) -- heads never straddle a 16-channel tile
+// here -- and the v rounds 32 channels each; a round's 14 x 16-byte loads per thread are issued before the
+// previous round's phase B and land in LDS after it (hardware zero fill outside the image, like rf_conv3x3.hip).
+// ================================================================================================
+struct AttnMidArgs {
+    const float* qkv;      // [B][3C][h][w]
+    float* v;              // [B][C][h][w]  depthwise-convolved v
+    float* partial;        // [B][nslab][C/16][16][66]  (layout of attn_front_kernel / rf_attn.hip)
+    const float* wd;       // [3C][9]
+    const float* bd;       // [3C]
+    int B, h, w, tiles_x, ntiles, nslab;
+};
+
+template <int C>
+__global__ void __launch_bounds__(256, 2) attn_mid_kernel(AttnMidArgs a) {
+    using namespace fused;
+    constexpr int NQT = C / 16;          // Gram rounds
+    constexpr int NVP = C / PART;        // v rounds
+    constexpr int NR = NQT + NVP;
+    constexpr int PSG = 452, PSV = 448, ROWW = 4 * 16 + 2;
+    constexpr int NF4 = PART * HR * (HC / 4);            // 16-byte elements of one staged round (32 planes x 6 x 18)
+    constexpr int FPT = (NF4 + 255) / 256;
+    constexpr unsigned OOB = 0x80000000u;
+    __shared__ __attribute__((aligned(16))) float mid[PART * PSG + 8];
+    __shared__ float wd_l[3 * C * 9], bd_l[3 * C];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int j = lane & 15, kq = lane >> 4;
+    const int slab = blockIdx.x, b = blockIdx.y;
+    const int h = a.h, w = a.w, P = h * w;
+    const float* qb = a.qkv + (size_t)b * 3 * C * P;
+    float* vb = a.v + (size_t)b * C * P;
+    for (int i = tid; i < 3 * C * 9; i += 256) wd_l[i] = a.wd[i];
+    for (int i = tid; i < 3 * C; i += 256) bd_l[i] = a.bd[i];
+
+    // element e = tid + 256 i of a round = (plane p, halo row, 4-pixel group g)
+    int pk[FPT];
+#pragma unroll
+    for (int i = 0; i < FPT; ++i) {
+        const int e = tid + 256 * i;
+        const int pl = e / (HR * (HC / 4)), rem = e % (HR * (HC / 4));
+        pk[i] = e < NF4 ? (pl << 16) | ((rem / (HC / 4)) << 8) | (rem % (HC / 4)) : -1;
+    }
+    unsigned voff[FPT];       // current tile: byte offset of (row, group) inside a plane, OOB outside the image
+    auto plan_tile = [&](int tile) {
+        const int y0 = (tile / a.tiles_x) * TH, x0 = (tile % a.tiles_x) * TW;
+#pragma unroll
+        for (int i = 0; i < FPT; ++i) {
+            int e = pk[i];
+            asm volatile("" : "+v"(e));
+            const int y = y0 - 1 + ((e >> 8) & 255), x = x0 - 4 + 4 * (e & 255);
+            const bool ok = e >= 0 && (unsigned)y < (unsigned)h && (unsigned)x < (unsigned)w;      // w % 4 == 0: whole groups
+            voff[i] = ok ? (unsigned)((y * w + x) * 4) : OOB;
+        }
+    };
+    float4 stg[FPT];
+    // round rd < NQT: q tile rd | k tile rd;  rd >= NQT: v channels 32 (rd - NQT) ..
+    auto load_round = [&](int rd) {
+        const bool gram = rd < NQT;
+        const size_t base = gram ? (size_t)16 * rd * P : (size_t)(2 * C + PART * (rd - NQT)) * P;
+        const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
+            const_cast<float*>(qb) + base, 0, (int)(((size_t)3 * C * P - base) * 4), 0x00020000);
+        const unsigned kjump = gram ? (unsigned)((C - 16) * P) * 4u : 0u;      // planes 16-31 of a Gram round are the k tile
+#pragma unroll
+        for (int i = 0; i < FPT; ++i) {
+            const int pl = pk[i] >> 16;
+            const unsigned off = voff[i] + (unsigned)pl * (unsigned)P * 4u + (pl >= 16 ? kjump : 0u);   // OOB stays >= 2^31
+            typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
+            const u32x4_t v4 = __builtin_amdgcn_raw_buffer_load_b128(rs, (int)off, 0, 0);
+            stg[i] = make_float4(__uint_as_float(v4.x), __uint_as_float(v4.y), __uint_as_float(v4.z), __uint_as_float(v4.w));
+        }
+    };
+    auto store_round = [&](int rd) {
+        const int PSX = rd < NQT ? PSG : PSV;
+#pragma unroll
+        for (int i = 0; i < FPT; ++i) {
+            const int e = pk[i];
+            if (e >= 0) *reinterpret_cast<float4*>(mid + (e >> 16) * PSX + ((e >> 8) & 255) * HC + 4 * (e & 255)) = stg[i];
+        }
+    };
+
+    // Rounds are the OUTER loop and this workgroup's tiles the inner one, so one register set holds the Gram tile of the
+    // round across all tiles (a round index into a register array would go to scratch); (round, tile) is one flattened
+    // pipeline: the next step's loads are issued before this step's phase B.
+    if (slab >= a.ntiles) return;                          // (whole workgroup)
+    const int ntw = (a.ntiles - slab + a.nslab - 1) / a.nslab;      // tiles of this workgroup: slab, slab + nslab, ...
+    f32x4 gq = {0.f, 0.f, 0.f, 0.f}, gnq = gq, gnk = gq;
+    plan_tile(slab);
+    load_round(0);
+    __syncthreads();                                      // wd_l / bd_l visible
+    for (int rd = 0; rd < NR; ++rd) {
+        for (int ti = 0; ti < ntw; ++ti) {
+            const int tile = slab + ti * a.nslab;
+            const int x0 = (tile % a.tiles_x) * TW, y0 = (tile / a.tiles_x) * TH;
+            const int yo = y0 + wave;
+            lds_barrier();                                // everyone is done reading the previous step
+            store_round(rd);
+            if (ti + 1 < ntw) {                           // next step: same round, next tile / next round, first tile
+                plan_tile(tile + a.nslab);
+                load_round(rd);
+            } else if (rd + 1 < NR) {
+                plan_tile(slab);
+                load_round(rd + 1);
+            }
+            lds_barrier();
+            if (rd < NQT) {
+                // Gram: lane (i = j, kq) owns channel j of the q tile and of the k tile at pixels x0 + 16 st + 4 kq + m
+                const int cq = 16 * rd + j, ck = C + 16 * rd + j;
+#pragma unroll
+                for (int st = 0; st < 4; ++st) {
+                    const int xo = x0 + 16 * st + 4 * kq;
+                    const bool ok = yo < h && xo < w;
+                    float qa[4], kb[4];
+                    stencil4_wide(mid + j * PSG + wave * HC + 16 * st + 4 * kq + 4, wd_l + cq * 9, bd_l[cq], qa);
+                    stencil4_wide(mid + (16 + j) * PSG + wave * HC + 16 * st + 4 * kq + 4, wd_l + ck * 9, bd_l[ck], kb);
+#pragma unroll
+                    for (int m = 0; m < 4; ++m) {
+                        const float qv = ok ? qa[m] : 0.f, kv = ok ? kb[m] : 0.f;
+                        gq = __builtin_amdgcn_mfma_f32_16x16x4f32(qv, kv, gq, 0, 0, 0);
+                        gnq = __builtin_amdgcn_mfma_f32_16x16x4f32(qv, qv, gnq, 0, 0, 0);
+                        gnk = __builtin_amdgcn_mfma_f32_16x16x4f32(kv, kv, gnk, 0, 0, 0);
+                    }
+                }
+            } else {
+                const int vp = rd - NQT, xo = x0 + 4 * j;
+                if (yo < h && xo < w) {
+#pragma unroll
+                    for (int s = 0; s < PART / 4; ++s) {
+                        const int hc = 4 * s + kq, cv = 2 * C + vp * PART + hc;
+                        float v[4];
+                        stencil4_dpp(mid + hc * PSV + wave * HC + 4 * j + 4, j, wd_l + cv * 9, bd_l[cv], v);
+                        *reinterpret_cast<float4*>(vb + (size_t)(vp * PART + hc) * P + (size_t)yo * w + xo) = make_float4(v[0], v[1], v[2], v[3]);
+                    }
+                }
+            }
+        }
+        if (rd < NQT) {
+            // ---- cross-wave reduction of this round's Gram tile in a fixed order, one partial per workgroup
+            // (the next step's data is still in registers: mid is free between the two barriers)
+            __syncthreads();
+            float* red = mid;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int row = 4 * kq + q;
+                float* rr = red + (wave * 16 + row) * ROWW;
+                rr[j] = gq[q];
+#pragma unroll
+                for (int c = 16; c < 64; c += 16) rr[c + j] = 0.f;
+                if (row == j) { rr[64] = gnq[q]; rr[65] = gnk[q]; }
+            }
+            __syncthreads();
+            float* dst = a.partial + (((size_t)b * a.nslab + slab) * NQT + rd) * 16 * ROWW;
+            for (int i = tid; i < 16 * ROWW; i += 256)
+                dst[i] = ((red[i] + red[16 * ROWW + i]) + red[2 * 16 * ROWW + i]) + red[3 * 16 * ROWW + i];
+            gq = (f32x4){0.f, 0.f, 0.f, 0.f}; gnq = gq; gnk = gq;
+        }
+    }
+}
+
+// slabs of the image (= workgroups per image): enough of them to fill the chip at a batch of 8, at most 8 tiles each;
+// a function of the image only (batch-invariant reduction order)
+int attn_mid_plan(int h, int w, int* nslab, size_t* partial_floats, int B, int C) {
+    const int ntiles = cdiv(w, fused::TW) * cdiv(h, fused::TH);
+    int per = ntiles / 64;
+    if (per < 1) per = 1;
+    if (per > 8) per = 8;
+    *nslab = cdiv(ntiles, per);
+    *partial_floats = (size_t)B * *nslab * (C / 16) * 16 * 66;
+    return RF_OK;
+}
+
+bool attn_mid_supported(int C, int heads, int h, int w) {
+    const int c = heads > 0 ? C / heads : 0;
+    return (C == 64 || C == 128) && heads > 0 && C % heads == 0 && c <= 16 && 16 % c == 0 && (w % 4 == 0) &&
+           ((double)3 * C * h * w * 4.0 < 2.0e9);
+}
+
+int launch_attn_mid(const float* qkv, float* v, float* partial, int nslab, const float* wd, const float* bd,
+                    int B, int C, int h, int w, hipStream_t st) {
+    RF_CHECK_ARG((C == 64 || C == 128) && w % 4 == 0 && B <= 65535, "attn_mid: unsupported shape C=%d %dx%d", C, h, w);
+    RF_CHECK_ARG(aligned16(qkv) && aligned16(v), "attn_mid: buffers must be 16-byte aligned");
+    AttnMidArgs a{qkv, v, partial, wd, bd, B, h, w, cdiv(w, fused::TW), 0, nslab};
+    a.ntiles = a.tiles_x * cdiv(h, fused::TH);
+    const double px = (double)B * h * w;
+    ProfScope prof(st, C == 64 ? "attn_mid_kernel<64>" : "attn_mid_kernel<128>", px * (54.0 * C + 4.0 * C * 16), px * 16.0 * C);
+    const dim3 grid((unsigned)nslab, (unsigned)B);
+    if (C == 64) attn_mid_kernel<64><<<grid, 256, 0, st>>>(a);
+    else attn_mid_kernel<128><<<grid, 256, 0, st>>>(a);
+    return check_launch("attn_mid");
+}
+
 #ifdef RF_STAMP
 extern "C" int rf_debug_stamps(unsigned long long* out8) {   // diagnostic build only: read and reset the phase cycle sums
     unsigned long long z[16] = {0};

@@ -165,6 +165,11 @@ int make_plan(const rf_handle* h, int B, int H, int W, Plan& p) {
             fused_attn_plan(H >> l, W >> l, &ns, &pf2, B, C);
             if (pf2 > gp) gp = pf2;
         }
+        if (attn_mid_supported(C, c.heads[l], H >> l, W >> l)) {
+            size_t pf2;
+            attn_mid_plan(H >> l, W >> l, &ns, &pf2, B, C);
+            if (pf2 > gp) gp = pf2;
+        }
         const size_t a = (size_t)B * packed1x1_floats(C, C), cr = (size_t)B * packed1x1_floats(2 * C, C);
         if (a > wa) wa = a;
         if (cr > wc) wc = cr;
