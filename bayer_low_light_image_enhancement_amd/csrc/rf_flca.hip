@@ -317,7 +317,15 @@ __global__ void __launch_bounds__(256) flca_se_kernel(const float* __restrict__ 
         float s = 0.f;
         if (sl < nsl && c < C) {
             const float* src = partial + b * nblk * C + c;
-            for (int k = sl; k < nblk; k += nsl) s += src[(size_t)k * C];
+            int k = sl;
+            for (; k + 7 * nsl < nblk; k += 8 * nsl) {      // 8 loads in flight, summed in block order
+                float t[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) t[u] = src[(size_t)(k + u * nsl) * C];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) s += t[u];
+            }
+            for (; k < nblk; k += nsl) s += src[(size_t)k * C];
         }
         part[threadIdx.x] = s;
         __syncthreads();
