@@ -39,6 +39,7 @@ SIGNATURES = {
     "rf_pack_params": (_i, [_vp, _vp, _sz, _vp]),
     "rf_workspace_bytes": (_i, [_vp, _i, _i, _i, _psz]),
     "rf_forward": (_i, [_vp, _vp, _vp, _vp, _sz, _i, _i, _i, _i, _vp]),
+    "rf_forward_stage": (_i, [_vp, _i, _vp, _vp, _vp, _vp, _sz, _i, _i, _i, _vp]),
     "rf_pixel_unshuffle2": (_i, [_vp, _vp, _i, _i, _i, _i, _vp]),
     "rf_pixel_shuffle2": (_i, [_vp, _vp, _i, _i, _i, _i, _vp]),
     "rf_dwt_haar": (_i, [_vp, _vp, _i, _i, _i, _i, _vp]),

@@ -15,6 +15,11 @@ from concurrent.futures import ThreadPoolExecutor
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(CSRC, "librawformer_hip.so")
+# Test-only twin of the library: the two host schedules recompiled with -DRF_DIAG, which adds the environment switches
+# RF_NO_FUSE / RF_NO_UPCAT (force the op-by-op schedule) so tests can compare the fused kernels with the un-fused chain.
+# The shipped library has no such switch.  Selected with RF_LIB_PATH (see _lib.py).
+DIAG_LIB = os.path.join(CSRC, "librawformer_hip_diag.so")
+DIAG_SOURCES = ["rf_block.hip", "rf_model.hip"]
 SOURCES = ["rf_api.hip", "rf_model.hip", "rf_pack.hip", "rf_pointwise.hip", "rf_gemm1x1.hip",
            "rf_conv3x3.hip", "rf_attn.hip", "rf_flca.hip", "rf_fused.hip", "rf_block.hip", "rf_harness.hip", "rf_tokattn.hip", "rf_wfb.hip", "rf_upcat.hip"]
 FLAGS = ["-O3", "-std=c++17", "-fPIC", "--offload-arch=gfx950", "-Wall", "-Wno-unused-function"]
@@ -62,5 +67,35 @@ def build_library(force: bool = False, verbose: bool = False) -> str:
     return LIB
 
 
+def build_diag_library(force: bool = False, verbose: bool = False) -> str:
+    """``librawformer_hip_diag.so`` = the product objects with rf_block / rf_model rebuilt under -DRF_DIAG."""
+    build_library(force=force, verbose=verbose)
+    hipcc = _hipcc()
+    headers = [os.path.join(CSRC, "rf_common.h"), os.path.join(HERE, "..", "include", "rawformer_hip.h")]
+    objs, rebuilt = [], False
+    for src in SOURCES:
+        s = os.path.join(CSRC, src)
+        if src in DIAG_SOURCES:
+            o = os.path.join(CSRC, src.replace(".hip", "_diag.o"))
+            if force or _stale(o, [s] + headers):
+                cmd = [hipcc, *FLAGS, "-DRF_DIAG", "-c", s, "-o", o]
+                if verbose:
+                    print(" ".join(cmd), flush=True)
+                r = subprocess.run(cmd, capture_output=True, text=True)
+                if r.returncode != 0:
+                    raise RuntimeError("hipcc failed:\n" + " ".join(cmd) + "\n" + r.stdout + r.stderr)
+                rebuilt = True
+        else:
+            o = os.path.join(CSRC, src.replace(".hip", ".o"))
+        objs.append(o)
+    if force or rebuilt or _stale(DIAG_LIB, objs):
+        r = subprocess.run([hipcc, "-shared", "-fPIC", "--offload-arch=gfx950", *objs, "-o", DIAG_LIB], capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError("hipcc link failed:\n" + r.stdout + r.stderr)
+    return DIAG_LIB
+
+
 if __name__ == "__main__":
     print(build_library(force="--force" in sys.argv, verbose=True))
+    if "--diag" in sys.argv:
+        print(build_diag_library(verbose=True))

@@ -227,10 +227,16 @@ int rf_convT2x2(const float* in, float* out, const float* weight, const float* b
 struct AttnScratch {
     size_t wqkv, pre, qkv, partial, wfold, total;
 };
-static int attn_scratch(int B, int C, int heads, int P, AttnScratch* s) {
+static int attn_scratch(int B, int C, int heads, int h, int w, AttnScratch* s) {
+    const int P = h * w;
     int ns, sl;
     size_t pf;
     RF_TRY(gram_plan(B, C, heads, P, &ns, &sl, &pf));
+    if (attn_mid_supported(C, heads, h, w)) {
+        size_t pf2;
+        attn_mid_plan(h, w, &ns, &pf2, B, C);
+        if (pf2 > pf) pf = pf2;
+    }
     size_t off = 0;
     auto take = [&](size_t f) { const size_t o = off; off += align_up(f, 64); return o; };
     s->wqkv = take(packed1x1_floats(C, 3 * C));
@@ -245,7 +251,7 @@ static int attn_scratch(int B, int C, int heads, int P, AttnScratch* s) {
 int rf_chan_attn_scratch_bytes(int B, int C, int heads, int h, int w, size_t* bytes) {
     RF_CHECK_ARG(bytes && B > 0 && C > 0 && heads > 0 && h > 0 && w > 0, "chan_attn_scratch_bytes: bad arguments");
     AttnScratch s;
-    RF_TRY(attn_scratch(B, C, heads, h * w, &s));
+    RF_TRY(attn_scratch(B, C, heads, h, w, &s));
     *bytes = s.total * sizeof(float);
     return RF_OK;
 }
@@ -258,26 +264,37 @@ int rf_chan_attn(const float* in, float* out, const float* qkv_w, const float* q
     hipStream_t st = (hipStream_t)stream;
     const int P = h * w;
     AttnScratch s;
-    RF_TRY(attn_scratch(B, C, heads, P, &s));
+    RF_TRY(attn_scratch(B, C, heads, h, w, &s));
     float* ws = (float*)scratch;
     RF_TRY(pack_1x1(qkv_w, ws + s.wqkv, 3 * C, C, C, 1, st));
     Conv1x1Args q{};
     q.x1 = in; q.C1 = C; q.x1_bstride = (int64_t)C * P; q.wp = ws + s.wqkv; q.bias = qkv_b;
     q.out = ws + s.pre; q.out_bstride = (int64_t)3 * C * P; q.Cout = 3 * C; q.B = B; q.P = P; q.w = w;
     RF_TRY(launch_conv1x1(q, st));
-    DwConvArgs d{};
-    d.x = ws + s.pre; d.x_bstride = (int64_t)3 * C * P; d.out = ws + s.qkv; d.out_bstride = (int64_t)3 * C * P;
-    d.w = dw_w; d.bias = dw_b; d.B = B; d.C = 3 * C; d.h = h; d.w_ = w;
-    RF_TRY(launch_dwconv3x3(d, st));
-    GramArgs g{};
-    g.q = ws + s.qkv; g.k = ws + s.qkv + (size_t)C * P; g.bstride = (int64_t)3 * C * P;
-    g.B = B; g.C = C; g.heads = heads; g.P = P; g.partial = ws + s.partial;
-    size_t pf;
-    RF_TRY(gram_plan(B, C, heads, P, &g.nslab, &g.slab, &pf));
-    RF_TRY(launch_gram(g, st));
-    RF_TRY(launch_attn_fold(g.partial, g.nslab, temperature, proj_w, ws + s.wfold, B, C, heads, st));
     Conv1x1Args av{};
-    av.x1 = ws + s.qkv + (size_t)2 * C * P; av.C1 = C; av.x1_bstride = (int64_t)3 * C * P;
+    int nslab = 0;
+    if (attn_mid_supported(C, heads, h, w)) {
+        // the forward's levels 1-2 kernel: depthwise 3x3 + Gram partials + v in one pass (rf_fused.hip)
+        size_t pf;
+        RF_TRY(attn_mid_plan(h, w, &nslab, &pf, B, C));
+        RF_TRY(launch_attn_mid(ws + s.pre, ws + s.qkv, ws + s.partial, nslab, dw_w, dw_b, B, C, h, w, st));
+        av.x1 = ws + s.qkv; av.x1_bstride = (int64_t)C * P;
+    } else {
+        DwConvArgs d{};
+        d.x = ws + s.pre; d.x_bstride = (int64_t)3 * C * P; d.out = ws + s.qkv; d.out_bstride = (int64_t)3 * C * P;
+        d.w = dw_w; d.bias = dw_b; d.B = B; d.C = 3 * C; d.h = h; d.w_ = w;
+        RF_TRY(launch_dwconv3x3(d, st));
+        GramArgs g{};
+        g.q = ws + s.qkv; g.k = ws + s.qkv + (size_t)C * P; g.bstride = (int64_t)3 * C * P;
+        g.B = B; g.C = C; g.heads = heads; g.P = P; g.partial = ws + s.partial;
+        size_t pf;
+        RF_TRY(gram_plan(B, C, heads, P, &g.nslab, &g.slab, &pf));
+        RF_TRY(launch_gram(g, st));
+        nslab = g.nslab;
+        av.x1 = ws + s.qkv + (size_t)2 * C * P; av.x1_bstride = (int64_t)3 * C * P;
+    }
+    RF_TRY(launch_attn_fold(ws + s.partial, nslab, temperature, proj_w, ws + s.wfold, B, C, heads, st));
+    av.C1 = C;
     av.wp = ws + s.wfold; av.wp_bstride = (int64_t)packed1x1_floats(C, C); av.bias = proj_b;
     av.out = out; av.out_bstride = (int64_t)C * P; av.Cout = C; av.B = B; av.P = P; av.w = w;
     return launch_conv1x1(av, st);
@@ -297,6 +314,7 @@ static void tb_scratch(int B, int C, int heads, int hc, int h, int w, TbScratch*
 
 int rf_transformer_block_scratch_bytes(int B, int C, int heads, int ffn_expansion, int h, int w, size_t* bytes) {
     RF_CHECK_ARG(bytes && B > 0 && C > 0 && heads > 0 && C % heads == 0 && ffn_expansion > 0 && h > 0 && w > 0, "transformer_block_scratch_bytes: bad arguments");
+    { int ns, sl; size_t pf; RF_TRY(gram_plan(B, C, heads, h * w, &ns, &sl, &pf)); }
     TbScratch s;
     tb_scratch(B, C, heads, C * ffn_expansion, h, w, &s);
     *bytes = s.total * sizeof(float);
@@ -310,6 +328,7 @@ int rf_transformer_block(const float* in, float* out, const float* const* prm, v
     for (int i = 0; i < 17; ++i) RF_CHECK_ARG(prm[i] != nullptr, "transformer_block: parameter %d is null", i);
     hipStream_t st = (hipStream_t)stream;
     const int hc = C * ffn_expansion;
+    { int ns, sl; size_t pf; RF_TRY(gram_plan(B, C, heads, h * w, &ns, &sl, &pf)); }
     TbScratch s;
     tb_scratch(B, C, heads, hc, h, w, &s);
     float* ws = (float*)scratch;

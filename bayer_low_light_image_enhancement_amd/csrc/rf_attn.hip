@@ -32,6 +32,14 @@ int gram_plan(int B, int C, int heads, int P, int* nslab, int* slab, size_t* par
     const int c = C / heads;
     RF_CHECK_ARG(c <= 64, "chan_attn: head size %d > 64 not supported", c);
     const int NTq = cdiv(C, 16);
+    // a 16-channel q tile may straddle heads when the head size is not 16-aligned; the k tiles it then needs must fit
+    // the partial row (kMaxBand tiles): c = 40 or 56 would need 5 / 7 and are rejected instead of computed wrongly
+    for (int tq = 0; tq < NTq; ++tq) {
+        int tklo, nb;
+        band_of(tq, C, c, &tklo, &nb);
+        RF_CHECK_ARG(nb <= kMaxBand, "chan_attn: C=%d with %d heads (head size %d) needs %d key tiles per query tile, at most %d supported",
+                     C, heads, c, nb, kMaxBand);
+    }
     // the slab split depends only on (C, P), never on B: an image's result is bitwise the same
     // alone and inside a batch
     int target = P / 16;                       // pixels per slab: at most 16 slabs per image (a slab's fixed cost -- ramp,

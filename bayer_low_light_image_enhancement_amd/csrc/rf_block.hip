@@ -22,7 +22,7 @@ size_t transformer_scratch_floats(int B, int C, int heads, int hc, int h, int w,
     o->x1 = take((size_t)B * C * P);
     int ns, sl;
     size_t pf = 0, pf2 = 0;
-    gram_plan(B, C, heads, (int)P, &ns, &sl, &pf);
+    if (gram_plan(B, C, heads, (int)P, &ns, &sl, &pf)) return 0;   // unsupported head layout: rf_last_error() says why
     if (fused_attn_supported(C, heads, h, w)) fused_attn_plan(h, w, &ns, &pf2, B, C);
     if (attn_mid_supported(C, heads, h, w)) attn_mid_plan(h, w, &ns, &pf2, B, C);
     o->partial = take(pf > pf2 ? pf : pf2);
@@ -38,7 +38,11 @@ int run_transformer(const TbParams& p, const float* in, float* out, float* ws, c
     float* x1 = ws + o.x1;
     float* partial = ws + o.partial;
     float* wfold = ws + o.wfold;
-    const bool no_fuse = getenv("RF_NO_FUSE") != nullptr;   // diagnostic: force the op-by-op path
+#ifdef RF_DIAG   // diagnostic build only (build.py --diag): force the op-by-op path; the shipped library has no switch
+    const bool no_fuse = getenv("RF_NO_FUSE") != nullptr;
+#else
+    constexpr bool no_fuse = false;
+#endif
 
     // x + attn(LN1(x)) ---------------------------------------------------------------------
     Conv1x1Args av{};

@@ -146,8 +146,10 @@ int make_plan(const rf_handle* h, int B, int H, int W, Plan& p) {
     p.tA = take(p, U0);
     p.tB = take(p, U0);
     p.tU = take(p, U0);
-    p.bufA = take(p, 3 * U0);
-    p.bufB = take(p, 3 * U0);
+    // widest TransformerBlock intermediate: qkv (3C) or the FFN hidden tensor (ffn_expansion * C) on the op-by-op path
+    const size_t wide = (size_t)(c.ffn_expansion > 3 ? c.ffn_expansion : 3);
+    p.bufA = take(p, wide * U0);
+    p.bufB = take(p, wide * U0);
     p.x1 = take(p, U0);
     p.trans = take(p, U0);
     p.xs = take(p, U0);
@@ -264,6 +266,9 @@ int rf_create(const rf_config* cfg, rf_handle** out) {
         const int C = cfg->dim << l;
         RF_CHECK_ARG(cfg->heads[l] > 0 && C % cfg->heads[l] == 0 && C / cfg->heads[l] <= 64,
                      "rf_create: heads[%d]=%d incompatible with %d channels (head size must divide and be <= 64)", l, cfg->heads[l], C);
+        int ns, sl;
+        size_t pf;
+        RF_TRY(gram_plan(1, C, cfg->heads[l], 256, &ns, &sl, &pf));   // rejects head sizes whose query tiles straddle too many key tiles
     }
     rf_handle* h = new rf_handle();
     h->cfg = *cfg;
@@ -381,6 +386,33 @@ int rf_workspace_bytes(const rf_handle* h, int B, int H, int W, size_t* bytes) {
     return RF_OK;
 }
 
+int rf_forward_stage(rf_handle* h, int stage, const float* in, const float* packed, float* out, void* workspace,
+                     size_t workspace_bytes, int B, int H, int W, void* stream) {
+    RF_CHECK_ARG(h && in && out && workspace && stage >= 1 && stage <= 7, "rf_forward_stage: bad arguments (stage 1..7)");
+    RF_CHECK_ARG(B > 0 && B <= 65535 && H > 0 && W > 0 && H % 8 == 0 && W % 8 == 0,
+                 "rf_forward_stage: packed size %dx%d must be positive multiples of 8", H, W);
+    RF_CHECK_ARG(h->cfg.variant != RF_VARIANT_FLCA || packed, "rf_forward_stage: the FLCA branch needs the packed frame for its guidance");
+    if (!h->packed) {
+        set_error("rf_forward_stage: parameters not packed (call rf_pack_params after rf_set_param)");
+        return RF_E_MISSING;
+    }
+    RF_CHECK_ARG(aligned16(workspace) && aligned16(in) && aligned16(out), "rf_forward_stage: buffers must be 16-byte aligned");
+    Plan p;
+    RF_TRY(make_plan(h, B, H, W, p));
+    if (workspace_bytes < p.total * sizeof(float)) {
+        set_error("rf_forward_stage: workspace of %zu bytes, need %zu", workspace_bytes, p.total * sizeof(float));
+        return RF_E_NOMEM;
+    }
+    hipStream_t st = (hipStream_t)stream;
+    float* ws = (float*)workspace;
+    const int lvl = stage <= 4 ? stage - 1 : 7 - stage;
+    if (h->cfg.variant == RF_VARIANT_FLCA) {
+        RF_TRY(launch_guidance_base(packed, 0, h->cfg.clamp_io, ws + p.gscratch, B, H, W, st));
+        RF_TRY(launch_guidance_level(ws + p.gscratch, ws + p.guide[lvl], B, H, W, H >> lvl, W >> lvl, st));
+    }
+    return run_stage(h, stage, lvl, in, out, ws, p, B, H, W, st);
+}
+
 int rf_forward(rf_handle* h, const float* in, float* out, void* workspace, size_t workspace_bytes,
                int B, int H, int W, int packed_input, void* stream) {
     RF_CHECK_ARG(h && in && out && workspace, "rf_forward: null argument");
@@ -432,7 +464,11 @@ int rf_forward(rf_handle* h, const float* in, float* out, void* workspace, size_
     for (int i = 1; i <= 3; ++i) {
         const int lvl = 3 - i, C = d << lvl, hh = H >> lvl, ww = W >> lvl, Pn = hh * ww;
         const std::string u = "up" + std::to_string(i), r = "channel_reduce" + std::to_string(i);
-        if (upcat_supported(C, hh / 2, ww / 2, ws + p.tB, skip[lvl], ws + p.tA) && getenv("RF_NO_UPCAT") == nullptr) {
+        bool fuse_up = upcat_supported(C, hh / 2, ww / 2, ws + p.tB, skip[lvl], ws + p.tA);
+#ifdef RF_DIAG   // diagnostic build only (build.py --diag): force the two-kernel decoder step
+        if (getenv("RF_NO_UPCAT")) fuse_up = false;
+#endif
+        if (fuse_up) {
             // ConvTranspose2d + cat + 1x1 as one kernel on composed weights: `up` never reaches HBM
             RF_TRY(launch_upcat(ws + p.tB, skip[lvl], ws + p.tA, h->packed + h->upcat_offset[i - 1], B, C, hh / 2, ww / 2, st));
             RF_TRY(run_stage(h, 4 + i, lvl, ws + p.tA, ws + p.tB, ws, p, B, H, W, st));

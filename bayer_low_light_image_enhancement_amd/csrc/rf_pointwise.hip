@@ -401,7 +401,7 @@ __global__ void __launch_bounds__(kBlock) dwconv3x3_kernel(DwConvArgs a) {
 int launch_dwconv3x3(const DwConvArgs& a, hipStream_t st) {
     const bool vec = (a.w_ & 3) == 0 && aligned16(a.x) && aligned16(a.out) && (a.x_bstride & 3) == 0 && (a.out_bstride & 3) == 0;
     const double el = (double)a.B * a.C * a.h * a.w_;
-    const bool tall = vec && a.h % 8 == 0 && getenv("RF_DW_ROWS4") == nullptr;   // 8 output rows per thread: 10 row loads per 8 rows instead of 6 per 4
+    const bool tall = vec && a.h % 8 == 0;   // 8 output rows per thread: 10 row loads per 8 rows instead of 6 per 4
     ProfScope prof(st, vec ? (tall ? "dwconv3x3_kernel<4, 8>" : "dwconv3x3_kernel<4, 4>") : "dwconv3x3_kernel<1, 4>", 18.0 * el, 8.0 * el);
     if (tall) {
         const size_t items = (size_t)a.B * a.C * (a.h / 8) * (a.w_ / 4);

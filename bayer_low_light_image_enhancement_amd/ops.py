@@ -269,6 +269,33 @@ def flca_guidance(x4: torch.Tensor, size: Tuple[int, int]) -> torch.Tensor:
     return out
 
 
+def bayer_luma_chroma(x4: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor, torch.Tensor]:
+    """``BayerLumaChroma()(x4)`` -> ``(y, cr, cb)``, each ``[B,1,H,W]``
+    (FrequencyawareLumaChromaAttentionRAWFormer.py:79-97): the base planes the guidance kernels keep at the head of their
+    scratch area (include/rawformer_hip.h, rf_flca_guidance)."""
+    x4 = _chk(x4, "x4")
+    b, c, h, w = x4.shape
+    if c != 4:
+        raise RuntimeError("bayer_luma_chroma expects packed RGGB [B,4,H,W]")
+    lib = _lib.load()
+    sz = C.c_size_t()
+    _lib.check(lib.rf_guidance_scratch_bytes(b, h, w, C.byref(sz)), "rf_guidance_scratch_bytes")
+    scratch = _scratch(sz.value, x4)
+    out = torch.empty((b, 4, h, w), dtype=x4.dtype, device=x4.device)
+    with torch.cuda.device(x4.device):
+        _lib.check(lib.rf_flca_guidance(_ptr(x4), _ptr(out), _ptr(scratch), b, h, w, h, w, _stream(x4)), "rf_flca_guidance")
+    planes = scratch[: 3 * b * h * w * 4].view(torch.float32).reshape(3, b, 1, h, w)
+    return planes[0].clone(), planes[1].clone(), planes[2].clone()
+
+
+def conv_ffn(x: torch.Tensor, pw1_w, pw1_b, dw_w, dw_b, pw2_w, pw2_b) -> torch.Tensor:
+    """``conv_ffn(dim, expansion)(x)`` = 1x1 -> depthwise 3x3 -> GELU -> 1x1
+    (FrequencyawareLumaChromaAttentionRAWFormer.py:190-209, RawFomer_WFB_FFAB/model.py:319-336), as the three kernels
+    the forward launches for it at U-Net levels 1-3 (level 0 runs it inside the fused FFN kernel together with
+    LayerNorm and the residual: ``transformer_block``)."""
+    return conv1x1(dwconv3x3(conv1x1(x, pw1_w, pw1_b), dw_w, dw_b, gelu=True), pw2_w, pw2_b)
+
+
 _TB_KEYS = ("norm1.body.weight", "norm1.body.bias", "attn.temperature", "attn.qkv.weight", "attn.qkv.bias",
             "attn.qkv_dwconv.weight", "attn.qkv_dwconv.bias", "attn.project_out.weight", "attn.project_out.bias",
             "norm2.body.weight", "norm2.body.bias", "ffn.pointwise1.weight", "ffn.pointwise1.bias",

@@ -41,13 +41,15 @@ def _cuts(n: int, parts: int) -> List[int]:
     return pts
 
 
-def _span(lo: int, hi: int, n: int, overlap: int) -> Tuple[int, int]:
+def _span(lo: int, hi: int, n: int, overlap: int, align: int = ALIGN) -> Tuple[int, int]:
     """Source interval covering [lo, hi) plus ``overlap`` on each side, length a multiple of
-    ALIGN, start even, clipped to [0, n)."""
+    ``align`` (of ALIGN when the aligned length would not fit the frame), start even, clipped to [0, n)."""
     a = max(0, lo - overlap)
     a -= a % 2
     b = min(n, hi + overlap)
-    length = -(-(b - a) // ALIGN) * ALIGN
+    length = -(-(b - a) // align) * align
+    if length > n:
+        length = -(-(b - a) // ALIGN) * ALIGN
     if length > n:
         raise ValueError(f"frame side {n} is not a multiple of {ALIGN} and too small to tile")
     if a + length > n:            # grow to the left instead of past the border
@@ -56,18 +58,22 @@ def _span(lo: int, hi: int, n: int, overlap: int) -> Tuple[int, int]:
     return a, length
 
 
-def plan_tiles(height: int, width: int, grid: Tuple[int, int], overlap: int = 32) -> List[Tile]:
+def plan_tiles(height: int, width: int, grid: Tuple[int, int], overlap: int = 32, align: int = ALIGN) -> List[Tile]:
     """Cut a ``height x width`` mosaic into ``grid = (rows, cols)`` tiles with ``overlap`` mosaic
     pixels of context on interior edges.  Works for sizes such as 2848x4256 (SID Sony) whose
-    eighth/sixteenth parts are not integers: tile sources are grown to a multiple of 16."""
+    eighth/sixteenth parts are not integers: tile sources are grown to a multiple of ``align``
+    (16 is what the model needs; 64 keeps every U-Net level of a tile a multiple of 4 pixels wide,
+    i.e. on the 16-byte vector paths of the kernels)."""
     if height % 2 or width % 2:
         raise ValueError("mosaic size must be even")
+    if align % ALIGN:
+        raise ValueError(f"align must be a multiple of {ALIGN}")
     ys, xs = _cuts(height, grid[0]), _cuts(width, grid[1])
     tiles = []
     for i in range(grid[0]):
         for j in range(grid[1]):
-            y0, hh = _span(ys[i], ys[i + 1], height, overlap)
-            x0, ww = _span(xs[j], xs[j + 1], width, overlap)
+            y0, hh = _span(ys[i], ys[i + 1], height, overlap, align)
+            x0, ww = _span(xs[j], xs[j + 1], width, overlap, align)
             dst = (ys[i], xs[j], ys[i + 1] - ys[i], xs[j + 1] - xs[j])
             tiles.append(Tile((y0, x0, hh, ww), dst, (dst[0] - y0, dst[1] - x0, dst[2], dst[3])))
     return tiles

@@ -1,28 +1,45 @@
 #!/usr/bin/env python3
-"""RawFormer-S inference throughput on MI355X: megapixels/s, RAW -> sRGB.
+"""RawFormer inference throughput on MI355X: megapixels/s, RAW -> sRGB.
 
 A step = one ``RawFormer.forward`` (HIP path) over one batch of synthetic low-light Bayer
-frames already resident in HBM.  The N = 1 workload is BASELINE.json configs[1]:
-RawFormer-S (dim 32), batch 8 of packed 4x512x512 (mosaic 1x1024x1024).  With ``--gpus N``
-(launched by torch.distributed.run, one rank per GPU) every rank runs the same per-GPU batch
-on its own images: the path shards along the batch with no data-path collective (weak
-scaling); the only collectives are the timing barrier and the MAX over ranks.
+frames already resident in HBM.  The default workload is BASELINE.json configs[1]:
+RawFormer-S (dim 32), batch 8 of packed 4x512x512 (mosaic 1x1024x1024) per GPU.
+
+Multi-GPU (one process per GPU, RCCL):
+  * ``python bench.py --gpus N`` with no WORLD_SIZE in the environment starts the N ranks itself
+    (a ``torch.distributed.run`` child; this parent never touches the GPU), relays rank 0's JSON line
+    and exits non-zero when fewer than N ranks took part.  Launched BY ``torch.distributed.run`` it is
+    one of the ranks; WORLD_SIZE must then equal ``--gpus``.
+  * cfg1/cfg2/cfg3/frame1: every rank runs the per-GPU batch on its own images -- the path shards along
+    the batch with no data-path collective (weak scaling; only the timing barrier and the MAX over
+    ranks use RCCL).
+  * cfg4 (RawFormer-L, one SID Sony frame 1x4x1424x2128): N = 1 runs the whole frame; N > 1 cuts it
+    into N overlapping tiles (multiples of 64 mosaic px), rank r runs tile r and ONE all-gather of the
+    tile outputs stitches the sRGB frame on every rank -- the collective is INSIDE the timed region
+    (strong scaling: the frame is fixed).
 
 Rank 0 prints ONE JSON line.  Besides the driver's fields it carries
   roofline      the dominant kernel (largest share of the forward), timed live with HIP events
                 on the launch stream (rf_profile_begin/end) over the same K steps in a second,
-                untimed pass, priced against its algorithmic FLOPs;
+                untimed pass, priced against its algorithmic FLOPs / bytes;
   cpu_baseline  the CPU oracle (oracle/rawformer_ref.py, torch CPU ops, all host cores) on a
                 bounded sample of the same workload, rank 0 at N = 1 only;
   kernels       the per-kernel-class breakdown of that profiled pass (share of forward time);
   dwt_roofline  the stand-alone DWT / IDWT kernels at the stage-0 activation size.
+
+``--dry-run`` (CPU, gloo, a stand-in forward) exercises the launcher, rendezvous, sharding, the
+tiled all-gather and the timing reduction without a GPU; its line says ``"dry_run": true`` and is
+not a measurement.
 """
 from __future__ import annotations
 
 import argparse
 import ctypes
+import glob
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -38,9 +55,57 @@ WORKLOADS = {
     "cfg2": (32, 8, 1024, 1024, "RawFormer-S(FLCA) dim=32, batch=8 of packed 4x512x512 synthetic Bayer per GPU"),
     "cfg1": (32, 1, 256, 256, "RawFormer-S(FLCA) dim=32, one packed 4x128x128 frame"),
     "cfg3": (48, 8, 1024, 1024, "RawFormer-B(FLCA) dim=48, batch=8 of packed 4x512x512 synthetic Bayer per GPU"),
+    "cfg4": (64, 1, 2848, 4256, "RawFormer-L(FLCA) dim=64, one SID Sony full frame, packed 4x1424x2128"),
+    "frame1": (32, 1, 1024, 1024, "RawFormer-S(FLCA) dim=32, ONE packed 4x512x512 frame (test.py:72 batch_size=1)"),
 }
+TILE_GRIDS = {1: (1, 1), 2: (1, 2), 3: (1, 3), 4: (2, 2), 5: (1, 5), 6: (2, 3), 7: (1, 7), 8: (2, 4)}
+TILE_OVERLAP = 64   # mosaic px of context per interior tile edge (tests/golden/tiling_psnr.json quantifies 32/64/128)
+TILE_ALIGN = 64     # tile sizes are multiples of 64 mosaic px: level 3 stays on the 16-byte vector paths
 
 
+def log(msg):
+    print(f"[bench {time.strftime('%H:%M:%S')}] {msg}", file=sys.stderr, flush=True)
+
+
+# --------------------------------------------------------------------------------------------- launcher
+def _free_port() -> int:
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def launch_ranks(n: int, argv) -> int:
+    """Parent of an N-rank run.  Nothing here initialises HIP (no torch.cuda call, no library load): the ranks
+    are CHILD processes of ``torch.distributed.run``, never a re-exec of a process that has touched the GPU."""
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC only on this host driver (RCCL needs it)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}",
+           "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), os.path.abspath(__file__), *argv]
+    log(f"starting {n} ranks: {' '.join(cmd[1:8])} bench.py {' '.join(argv)}")
+    proc = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, text=True)
+    line = None
+    for ln in proc.stdout.splitlines():
+        ln = ln.strip()
+        if ln.startswith("{") and ln.endswith("}"):
+            try:
+                line = json.loads(ln)
+            except ValueError:
+                continue
+    if proc.returncode != 0:
+        sys.stdout.write(proc.stdout)
+        log(f"rank launch failed with exit code {proc.returncode}")
+        return proc.returncode or 1
+    if line is None or line.get("n_gpus") != n:
+        sys.stdout.write(proc.stdout)
+        log(f"expected a result from {n} ranks, got {None if line is None else line.get('n_gpus')}")
+        return 3
+    print(json.dumps(line), flush=True)
+    return 0
+
+
+# --------------------------------------------------------------------------------------------- measurement helpers
 def profile_pass(fn, steps):
     """Run ``fn`` ``steps`` times with every kernel launch bracketed by HIP events."""
     import torch
@@ -57,19 +122,42 @@ def profile_pass(fn, steps):
     return json.loads(buf.value.decode())
 
 
+def issued_over_algorithmic(kernel: str) -> float:
+    """MFMA flops the kernel ISSUES per algorithmic flop.  The 3x3 convolutions use the Winograd F(4,3) form along x:
+    6 products per 4 outputs x 3 taps instead of 12."""
+    return 0.5 if kernel.startswith("conv3x3_kernel") else 1.0
+
+
 def roofline_of(rec):
+    """``achieved`` = algorithmic work / measured time.  ``peak`` is the roof for THAT work:
+    8 TB/s for HBM-bound kernels; for MFMA-bound ones the f32 matrix peak divided by the issued/algorithmic ratio of
+    the kernel's algorithm, so ``frac`` = matrix-pipe utilisation and can never exceed 1."""
     ms = rec["ms"] / rec["launches"]
     flops, byts = rec["flops"] / rec["launches"], rec["bytes"] / rec["launches"]
     intensity = flops / max(byts, 1.0)
     if intensity >= PEAK_F32_MFMA_TFLOPS * 1e12 / (PEAK_HBM_GBS * 1e9):
+        ratio = issued_over_algorithmic(rec["kernel"])
         ach = flops / (ms * 1e-3) / 1e12
-        return {"kernel": rec["kernel"], "bound": "mfma", "achieved": round(ach, 3), "peak": PEAK_F32_MFMA_TFLOPS,
-                "unit": "TFLOP/s", "frac": round(ach / PEAK_F32_MFMA_TFLOPS, 4), "traffic": None,
-                "avg_launch_us": round(ms * 1e3, 2), "launches_per_step": None}
+        peak = PEAK_F32_MFMA_TFLOPS / ratio
+        return {"kernel": rec["kernel"], "bound": "mfma", "achieved": round(ach, 3), "peak": round(peak, 1),
+                "unit": "TFLOP/s", "frac": round(ach / peak, 4), "traffic": None,
+                "avg_launch_us": round(ms * 1e3, 2), "launches_per_step": None,
+                "mfma_peak_f32": PEAK_F32_MFMA_TFLOPS, "mfma_flops_issued_over_algorithmic": ratio,
+                "issued_tflops": round(ach * ratio, 3)}
     ach = byts / (ms * 1e-3) / 1e9
     return {"kernel": rec["kernel"], "bound": "hbm", "achieved": round(ach, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s",
             "frac": round(ach / PEAK_HBM_GBS, 4), "traffic": None, "avg_launch_us": round(ms * 1e3, 2),
             "launches_per_step": None}
+
+
+def _latest_profile(suffix: str):
+    files = sorted(glob.glob(os.path.join(REPO, "profiles", f"*_{suffix}.json")))
+    if not files:
+        return None
+    try:
+        return json.load(open(files[-1]))
+    except Exception:
+        return None
 
 
 def pmc_traffic(kernel, workload):
@@ -79,15 +167,19 @@ def pmc_traffic(kernel, workload):
     the profiled one or the kernel is not in the file."""
     if workload != "cfg2":
         return None
-    import glob
-    files = sorted(glob.glob(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "*_traffic.json")))
-    if not files:
+    d = _latest_profile("traffic")
+    rec = (d or {}).get("kernels", {}).get(kernel)
+    return rec["hbm_bytes_per_launch"] if rec else None
+
+
+def pmc_mfma_util(kernel, workload):
+    """Matrix-pipe busy fraction of ``kernel`` from the committed SQ-counter pass (profiles/*_mfma_util.json,
+    made by tools/mfma_util.py from ``rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES ...``)."""
+    if workload != "cfg2":
         return None
-    try:
-        rec = json.load(open(files[-1]))["kernels"].get(kernel)
-        return rec["hbm_bytes_per_launch"] if rec else None
-    except Exception:
-        return None
+    d = _latest_profile("mfma_util")
+    rec = (d or {}).get("kernels", {}).get(kernel)
+    return rec.get("mfma_busy_frac") if rec else None
 
 
 def host_cores() -> int:
@@ -113,8 +205,14 @@ def host_cores() -> int:
     return cores
 
 
-def log(msg):
-    print(f"[bench {time.strftime('%H:%M:%S')}] {msg}", file=sys.stderr, flush=True)
+def cpu_model() -> str:
+    try:
+        for ln in open("/proc/cpuinfo"):
+            if ln.lower().startswith("model name"):
+                return ln.split(":", 1)[1].strip()
+    except Exception:
+        pass
+    return "unknown"
 
 
 def cpu_baseline(dim, hm, wm, sd):
@@ -126,7 +224,10 @@ def cpu_baseline(dim, hm, wm, sd):
     cores = host_cores()
     torch.set_num_threads(cores)
     cfg = R.RawFormerConfig(dim=dim)
-    sd_cpu = {k: v.cpu() for k, v in sd.items()}
+    sd_cpu = {k: v.detach().cpu() for k, v in sd.items()}
+    base = {"unit": "MP/s", "cores": cores, "kind": "port", "cpu": cpu_model()}
+    if hm * wm > 4 << 20:   # full SID frame: a 1024x1024 crop of it bounds the sample (the oracle is per-pixel work)
+        hm, wm = 1024, 1024
     x1 = torch.from_numpy(synth.bayer_mosaic(900, 1, hm, wm))
     with torch.no_grad():
         t0 = time.perf_counter()
@@ -134,8 +235,8 @@ def cpu_baseline(dim, hm, wm, sd):
         t_one = time.perf_counter() - t0
         log(f"cpu_baseline: warm-up frame took {t_one:.2f} s on {cores} threads")
         if t_one > 15.0:   # slow host: the warm-up frame itself is the bounded sample
-            return {"value": round(hm * wm / 1e6 / t_one, 4), "unit": "MP/s", "cores": cores, "kind": "port",
-                    "sample": f"1 frame of 1x{hm}x{wm} mosaic, torch CPU fp32 oracle, single cold run, {cores} threads"}
+            return dict(base, value=round(hm * wm / 1e6 / t_one, 4),
+                        sample=f"1 frame of 1x{hm}x{wm} mosaic, torch CPU fp32 oracle, single cold run, {cores} threads")
         nimg = int(max(1, min(8, 12.0 // max(t_one, 1e-3))))
         x = torch.from_numpy(synth.bayer_mosaic(901, nimg, hm, wm))
         times = []
@@ -144,8 +245,8 @@ def cpu_baseline(dim, hm, wm, sd):
             R.rawformer_forward(sd_cpu, x, cfg)
             times.append(time.perf_counter() - t0)
     best = min(times)
-    return {"value": round(nimg * hm * wm / 1e6 / best, 4), "unit": "MP/s", "cores": cores, "kind": "port",
-            "sample": f"{nimg} frame(s) of 1x{hm}x{wm} mosaic, torch CPU fp32 oracle, best of 2 after warm-up, {cores} threads"}
+    return dict(base, value=round(nimg * hm * wm / 1e6 / best, 4),
+                sample=f"{nimg} frame(s) of 1x{hm}x{wm} mosaic, torch CPU fp32 oracle, best of 2 after warm-up, {cores} threads")
 
 
 def dwt_microbench(device):
@@ -168,6 +269,19 @@ def dwt_microbench(device):
     return res
 
 
+def synthetic_state(model, seed):
+    """Seeded weights for every parameter the library's registry (rf_param_info) declares, by name and shape; the
+    module's constant buffers (luma weights, Haar filters) keep the values its constructor gave them."""
+    import torch
+    from bayer_low_light_image_enhancement_amd import synth
+
+    sd = model.state_dict()
+    for k, p in model.named_parameters():
+        sd[k] = torch.from_numpy(synth.param_values(seed, k, tuple(p.shape))).reshape(p.shape)
+    return sd
+
+
+# --------------------------------------------------------------------------------------------- main
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -176,47 +290,94 @@ def main():
     ap.add_argument("--workload", default="cfg2", choices=sorted(WORKLOADS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile", action="store_true")
+    ap.add_argument("--dry-run", action="store_true", help="CPU + gloo + stand-in forward: launcher / sharding / collective rehearsal")
     args = ap.parse_args()
+    if args.gpus < 1:
+        raise SystemExit("--gpus must be >= 1")
+
+    env_world = os.environ.get("WORLD_SIZE")
+    if env_world is None and args.gpus > 1:
+        raise SystemExit(launch_ranks(args.gpus, sys.argv[1:]))      # BEFORE any torch.cuda / HIP call in this process
+    world = int(env_world or "1")
+    if world != args.gpus:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but the launcher provides WORLD_SIZE={world}; refusing to report a "
+                         f"run of {world} rank(s) as {args.gpus}")
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
 
     import torch
     import torch.distributed as dist
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local = int(os.environ.get("LOCAL_RANK", "0"))
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs a ROCm device: the RawFormer HIP path has no CPU fallback")
-    torch.cuda.set_device(local)
-    device = torch.device("cuda", local)
+    if args.dry_run:
+        device = torch.device("cpu")
+        torch.set_num_threads(2)
+    else:
+        if torch.cuda.device_count() <= local:
+            raise SystemExit(f"bench.py: rank {rank} needs GPU {local} but only {torch.cuda.device_count()} device(s) are visible "
+                             "(the RawFormer HIP path has no CPU fallback)")
+        torch.cuda.set_device(local)
+        device = torch.device("cuda", local)
     use_dist = world > 1 or "TORCHELASTIC_RUN_ID" in os.environ   # under torchrun the RCCL path is taken even for one rank
     if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
-        dist.init_process_group("nccl", device_id=device)
+        if args.dry_run:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=device)
+        if dist.get_world_size() != args.gpus:
+            raise SystemExit(f"bench.py: {dist.get_world_size()} ranks joined, expected {args.gpus}")
 
-    from bayer_low_light_image_enhancement_amd import RawFormer, synth
-    from oracle.rawformer_ref import RawFormerConfig, param_shapes   # shapes only; the oracle is not run here
+    from bayer_low_light_image_enhancement_amd import synth, tiling
 
     dim, batch, hm, wm, desc = WORKLOADS[args.workload]
-    shapes = param_shapes(RawFormerConfig(dim=dim))
-    sd = {k: torch.from_numpy(synth.param_values(100 + dim, k, s)).reshape(s) for k, s in shapes.items()}
-    model = RawFormer(dim=dim)
-    model.load_state_dict(sd, strict=False)
-    model = model.to(device).eval()
-    # this rank's images: seeds are disjoint across ranks
-    x = torch.from_numpy(synth.bayer_mosaic(2 + rank * batch, batch, hm, wm)).to(device)
+    tiled = args.workload == "cfg4" and world > 1
+    if args.dry_run:
+        if args.workload == "cfg4":
+            hm, wm = 2848 // 4 // 16 * 16, 4256 // 4 // 16 * 16     # a quarter-size frame keeps the rehearsal fast
+        else:
+            hm, wm = hm // 8, wm // 8
+        sd = {}
 
-    def step():
-        with torch.no_grad():
-            return model(x)
+        def forward(t):   # stand-in of the right shape; NOT the model (no GPU here)
+            return t.repeat(1, 3, 1, 1) * 0.5
+    else:
+        from bayer_low_light_image_enhancement_amd import RawFormer
+        model = RawFormer(dim=dim)
+        sd = synthetic_state(model, 100 + dim)
+        model.load_state_dict(sd, strict=True)
+        model = model.to(device).eval()
+
+        def forward(t):
+            return model(t)
+
+    if tiled:
+        # strong scaling: ONE frame (same seed on every rank), N tiles, one per rank, one all-gather
+        x = torch.from_numpy(synth.bayer_mosaic(10, 1, hm, wm)).to(device)
+        tiles = tiling.plan_tiles(hm, wm, TILE_GRIDS[world], overlap=TILE_OVERLAP, align=TILE_ALIGN)
+        assert len(tiles) == world
+
+        def step():
+            with torch.no_grad():
+                return tiling.forward_full_frame_sharded(forward, x, tiles)
+    else:
+        # this rank's images: seeds are disjoint across ranks
+        seed0 = 10 if args.workload == "cfg4" else 2 + rank * batch
+        x = torch.from_numpy(synth.bayer_mosaic(seed0, batch, hm, wm)).to(device)
+
+        def step():
+            with torch.no_grad():
+                return forward(x)
 
     def fence():
-        torch.cuda.synchronize()
+        if not args.dry_run:
+            torch.cuda.synchronize()
         if use_dist:
             dist.barrier()
-        torch.cuda.synchronize()
+        if not args.dry_run:
+            torch.cuda.synchronize()
 
-    log(f"rank {rank}/{world}: model and {batch} frame(s) of {hm}x{wm} resident on {device}")
+    log(f"rank {rank}/{world}: model and {batch} frame(s) of {hm}x{wm} resident on {device}" + (f", {len(tiles)} tiles" if tiled else ""))
     for _ in range(args.warmup):
         step()
     fence()
@@ -231,9 +392,10 @@ def main():
         elapsed = float(t.item())
     assert torch.isfinite(out).all()
 
-    mp_per_step = world * batch * hm * wm / 1e6
+    mp_per_step = (1 if tiled else world) * batch * hm * wm / 1e6
+    model_name = {32: "S", 48: "B", 64: "L"}[dim]
     line = {
-        "metric": "megapixels/sec RawFormer-S 512x512 RAW->sRGB",
+        "metric": f"megapixels/sec RawFormer-{model_name} RAW->sRGB" if args.workload != "cfg2" else "megapixels/sec RawFormer-S 512x512 RAW->sRGB",
         "value": round(mp_per_step * args.steps / elapsed, 3),
         "unit": "MP/s",
         "n_gpus": world,
@@ -241,40 +403,47 @@ def main():
         "warmup": args.warmup,
         "ms_per_step": round(elapsed / args.steps * 1e3, 4),
         "higher_is_better": True,
-        "scaling": "weak",
+        "scaling": "strong" if args.workload == "cfg4" else "weak",
         "vs_baseline": None,
         "dtype": "f32",
         "data": "synthetic",
-        "config": {"workload": desc, "frames_per_gpu": batch, "mosaic": [hm, wm], "packed": [4, hm // 2, wm // 2],
-                   "variant": "flca", "weights": "synthetic (seeded, random-init scale)", "parallelism": f"batch-sharded x{world}",
-                   "device": torch.cuda.get_device_name(local)},
+        "config": {"workload": desc, "name": args.workload, "frames_per_gpu": batch, "mosaic": [hm, wm], "packed": [4, hm // 2, wm // 2],
+                   "variant": "flca", "weights": "synthetic (seeded, random-init scale)",
+                   "parallelism": (f"tile-sharded x{world} (grid {TILE_GRIDS[world][0]}x{TILE_GRIDS[world][1]}, overlap {TILE_OVERLAP}, "
+                                   f"all-gather of tile outputs inside the timed region)") if tiled else f"batch-sharded x{world}",
+                   "device": "cpu (dry run)" if args.dry_run else torch.cuda.get_device_name(local)},
     }
+    if args.dry_run:
+        line["dry_run"] = True
+        line["data"] = "synthetic; stand-in forward on CPU (launcher rehearsal, not a measurement)"
     log(f"timed region done: {elapsed / args.steps * 1e3:.3f} ms/step")
-    if rank == 0 and not args.no_profile:
-        recs = profile_pass(step, args.steps)
+    if rank == 0 and not args.no_profile and not args.dry_run:
+        prof_step = (lambda: forward(x)) if not tiled else step
+        with torch.no_grad():
+            recs = profile_pass(prof_step, args.steps)
         total = sum(r["ms"] for r in recs)
         recs.sort(key=lambda r: -r["ms"])
         top = recs[0]
         rl = roofline_of(top)
         rl["launches_per_step"] = top["launches"] // args.steps
         rl["traffic"] = pmc_traffic(top["kernel"], args.workload)
+        rl["mfma_util"] = pmc_mfma_util(top["kernel"], args.workload)
         rl["algorithmic_bytes_per_launch"] = round(top["bytes"] / top["launches"])
         rl["share_of_forward"] = round(top["ms"] / total, 4)
-        if top["kernel"].startswith("conv3x3_kernel"):
-            # `achieved` prices the ALGORITHMIC flops (18 Cin Cout per pixel); the kernel uses the Winograd
-            # F(4,3) form along x and issues half of them as MFMA work, so the matrix pipe itself runs at frac / 2 of peak
-            rl["mfma_flops_issued_over_algorithmic"] = 0.5
-            rl["frac_of_peak_issued"] = round(rl["frac"] * 0.5, 4)
         line["roofline"] = rl
         line["kernels"] = [{"kernel": r["kernel"], "launches_per_step": r["launches"] // args.steps,
                             "ms_per_step": round(r["ms"] / args.steps, 4), "share": round(r["ms"] / total, 4),
                             "tflops": round(r["flops"] / max(r["ms"], 1e-9) / 1e9, 2),
-                            "gbs": round(r["bytes"] / max(r["ms"], 1e-9) / 1e6, 1)} for r in recs]
+                            "gbs": round(r["bytes"] / max(r["ms"], 1e-9) / 1e6, 1),
+                            "frac": roofline_of(r)["frac"] if (r["flops"] or r["bytes"]) else None,
+                            "bound": roofline_of(r)["bound"] if (r["flops"] or r["bytes"]) else None,
+                            "traffic": pmc_traffic(r["kernel"], args.workload)} for r in recs]
         line["profiled_ms_per_step"] = round(total / args.steps, 4)
         log("profiled pass done")
-        line["dwt_roofline"] = dwt_microbench(device)
-        log("dwt microbench done")
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        if args.workload == "cfg2":
+            line["dwt_roofline"] = dwt_microbench(device)
+            log("dwt microbench done")
+    if rank == 0 and world == 1 and not args.no_cpu_baseline and not args.dry_run:
         line["cpu_baseline"] = cpu_baseline(dim, hm, wm, sd)
     if use_dist:
         dist.barrier()

@@ -80,7 +80,20 @@ int rf_workspace_bytes(const rf_handle* h, int B, int H, int W, size_t* bytes);
 int rf_forward(rf_handle* h, const float* in, float* out, void* workspace, size_t workspace_bytes,
                int B, int H, int W, int packed_input, void* stream);
 
-/* ---- operators (parity-test surface; the same kernels the forward uses) ------------------- */
+/* One Conv_Transformer stage of the model, exactly as rf_forward schedules it (branch || TransformerBlock -> cat ->
+ * 1x1 -> 3x3 -> LeakyReLU; FrequencyawareLumaChromaAttentionRAWFormer.py:257-278, RawFomer_WFB_FFAB/model.py:393-412,
+ * model.py:94-108), including the squeeze-excite fold into channel_reduce.  stage = 1..7 (conv_tran<stage>), at U-Net
+ * level l = stage-1 (encoder) or 7-stage (decoder): in/out [B, dim*2^l, H>>l, W>>l]; packed [B,4,H,W] feeds the FLCA
+ * guidance (may be NULL for the plain variant).  Workspace as for rf_forward(B, H, W). */
+int rf_forward_stage(rf_handle* h, int stage, const float* in, const float* packed, float* out, void* workspace,
+                     size_t workspace_bytes, int B, int H, int W, void* stream);
+
+/* ---- operators (parity-test surface) -----------------------------------------------------------
+ * Each entry runs the kernels the forward uses for that operator at that shape.  Where the forward
+ * fuses ACROSS operators the fused kernel belongs to the wider entry point: rf_chan_attn (no LayerNorm
+ * in its contract) takes the depthwise+Gram kernel of levels 1-2 (attn_mid) but not the level-0 kernel
+ * that also contains LayerNorm and the qkv 1x1 (attn_front) -- that one, and the fused FFN, are reached
+ * through rf_transformer_block. */
 /* downshuffle(var, 2): RawFomer_WFB_FFAB/model.py:287-298.  [B,C,2h,2w] -> [B,4C,h,w] */
 int rf_pixel_unshuffle2(const float* in, float* out, int B, int C, int h, int w, void* stream);
 /* nn.PixelShuffle(2): RawFomer_WFB_FFAB/model.py:471,507.    [B,4C,h,w] -> [B,C,2h,2w] */
@@ -146,7 +159,8 @@ int rf_flca(const float* feat, const float* guide, float* out, const float* cons
             int B, int C, int h, int w, void* stream);
 /* BayerLumaChroma + HaarDWT + bilinear resize = the guidance planes of FLCA
  * (FrequencyawareLumaChromaAttentionRAWFormer.py:79-97,138-149).
- * packed [B,4,H,W] -> guide [B,4,hf,wf] = (y_low, y_high, cr, cb); scratch >= rf_guidance_scratch_bytes. */
+ * packed [B,4,H,W] -> guide [B,4,hf,wf] = (y_low, y_high, cr, cb); scratch >= rf_guidance_scratch_bytes.
+ * On return the scratch area starts with the BayerLumaChroma output itself: y | cr | cb, each [B,H,W] floats. */
 int rf_guidance_scratch_bytes(int B, int H, int W, size_t* bytes);
 int rf_flca_guidance(const float* packed, float* guide, void* scratch, int B, int H, int W, int hf, int wf, void* stream);
 

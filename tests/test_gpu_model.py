@@ -171,10 +171,20 @@ def test_checkpoint_round_trip_and_param_update(device, tmp_path):
     m2.eval()
     with torch.no_grad():
         assert torch.equal(m2(x), y0)
-        # an in-place parameter update must be picked up (weights are re-packed)
-        m2.conv_out.bias.add_(0.25)
+        # an in-place update of a PACKED weight (conv_out.weight lives in the MFMA-ordered copy, not behind a borrowed
+        # pointer) must be picked up: the (data_ptr, _version) signature re-packs
+        m2.conv_out.weight.mul_(1.5)
         y1 = m2(x)
-    assert float((y1 - y0).abs().max()) > 1e-3
+        sd2 = {k: v.detach().cpu() for k, v in m2.state_dict().items()}
+        ref1 = R.rawformer_forward(sd2, x.cpu(), R.RawFormerConfig(dim=dim))
+        assert float((y1 - y0).abs().max()) > 1e-3 and maxabs(y1, ref1) <= TOL
+        # a write through .data does not move _version: invalidate_packed() is the documented hook
+        m2.conv_tran1.Transformer.attn.qkv.weight.data.mul_(0.5)
+        stale = m2(x)
+        m2.invalidate_packed()
+        y2 = m2(x)
+        sd3 = {k: v.detach().cpu() for k, v in m2.state_dict().items()}
+        assert torch.equal(stale, y1) and maxabs(y2, R.rawformer_forward(sd3, x.cpu(), R.RawFormerConfig(dim=dim))) <= TOL
 
 
 def test_baseline_config4_full_frame(device):
@@ -221,3 +231,59 @@ def test_full_frame_tiled_path_on_device(device):
     assert torch.equal(out[:, :, t.dst[0]:t.dst[0] + ch, t.dst[1]:t.dst[1] + cw], alone[:, :, cy:cy + ch, cx:cx + cw])
     assert maxabs(alone, ref) <= TOL
     assert torch.isfinite(out).all()
+
+
+def test_stage_entry_point_matches_reference_conv_transformer_golden(device):
+    """a3: the reference's Conv_Transformer outputs (per_op.npz: `conv_transformer_flca` from
+    FrequencyawareLumaChroma...py:257-278, `root_convtransformer` from model.py:94-108) through rf_forward_stage, i.e. the
+    very schedule the forward runs for a stage (fused kernels, squeeze-excite fold into channel_reduce)."""
+    from bayer_low_light_image_enhancement_amd import RawFormer
+    g = golden("per_op")
+    # FLCA flavour: C = 32 features at 16x24 guided by a packed 32x48 frame = stage 2 (level 1) of a dim-16 model
+    m = RawFormer(dim=16)
+    sd = m.state_dict()
+    sd.update(cases.model_state(16, 5))
+    sd.update({"conv_tran2." + k: v for k, v in cases.params(cases.conv_transformer_flca_spec(32)).items()})
+    m.load_state_dict(sd, strict=True)
+    m = m.to(device).eval()
+    with torch.no_grad():
+        out = m.forward_stage(2, cases.rnd("x.ct", (2, 32, 16, 24)).to(device), cases.rnd("x.packed", (2, 4, 32, 48), 0, 1).to(device))
+    assert maxabs(out, g["conv_transformer_flca"]) <= 2e-5
+    # root model.py flavour (plain 3x3 branch, no LeakyReLU on it, `scale` [1,8,1,1]): stage 1 of a dim-32 plain model
+    c = 32
+    root = {"conv.weight": (c, c, 3, 3), "conv.bias": (c,), "transformer.norm1.norm.weight": (c,),
+            "transformer.norm1.norm.bias": (c,), "transformer.attn.scale": (1, 8, 1, 1),
+            "transformer.attn.qkv.0.weight": (3 * c, c, 1, 1), "transformer.attn.qkv.0.bias": (3 * c,),
+            "transformer.attn.qkv.1.weight": (3 * c, 1, 3, 3), "transformer.attn.qkv.1.bias": (3 * c,),
+            "transformer.attn.proj.weight": (c, c, 1, 1), "transformer.attn.proj.bias": (c,),
+            "transformer.norm2.norm.weight": (c,), "transformer.norm2.norm.bias": (c,),
+            "transformer.ffn.net.0.weight": (2 * c, c, 1, 1), "transformer.ffn.net.0.bias": (2 * c,),
+            "transformer.ffn.net.1.weight": (2 * c, 1, 3, 3), "transformer.ffn.net.1.bias": (2 * c,),
+            "transformer.ffn.net.3.weight": (c, 2 * c, 1, 1), "transformer.ffn.net.3.bias": (c,),
+            "reduce.weight": (c, 2 * c, 1, 1), "reduce.bias": (c,), "out.0.weight": (c, c, 3, 3), "out.0.bias": (c,)}
+    m = RawFormer(dim=c, variant="plain", branch_lrelu=False)
+    sd = m.state_dict()
+    sd.update(cases.model_state(c, 6, "plain"))
+    sd.update({"module.encoder.0." + k: v for k, v in cases.params(root).items()})       # root-layout keys: translated on load
+    for k in [k for k in sd if k.startswith("conv_tran1.")]:
+        del sd[k]
+    m.load_state_dict(sd, strict=True)
+    m = m.to(device).eval()
+    with torch.no_grad():
+        out = m.forward_stage(1, cases.rnd("x.root", (2, c, 16, 16)).to(device))
+    assert maxabs(out, g["root_convtransformer"]) <= 2e-5
+
+
+def test_ffn_expansion_4_whole_model(device):
+    """ffn_expansion_factor = 4 used to overflow the 3C-wide scratch of the op-by-op FFN."""
+    from bayer_low_light_image_enhancement_amd import RawFormer
+    dim, seed = 16, 71
+    cfg = R.RawFormerConfig(dim=dim)
+    shapes = R.param_shapes(cfg, ffn_expansion_factor=4)      # the oracle's forward takes the hidden width from the weights
+    sd = {k: torch.from_numpy(synth.param_values(seed, k, s)).reshape(s) for k, s in shapes.items()}
+    m = RawFormer(dim=dim, ffn_expansion_factor=4)
+    m.load_state_dict({**m.state_dict(), **sd}, strict=True)
+    m = m.to(device).eval()
+    x = torch.from_numpy(synth.bayer_mosaic(seed, 2, 64, 96))
+    with torch.no_grad():
+        assert maxabs(m(x.to(device)), R.rawformer_forward(sd, x, cfg)) <= TOL

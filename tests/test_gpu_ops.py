@@ -265,3 +265,90 @@ def test_upsample_cat_reduce_matches_two_step_reference(device):
         ref = torch.nn.functional.conv2d(torch.cat([up, skip], 1), p["cr.weight"], p["cr.bias"])
         got = ops.upsample_cat_reduce(x.to(device), skip.to(device), *(p[k].to(device) for k in ("up.weight", "up.bias", "cr.weight", "cr.bias")))
         assert float((got.cpu() - ref).abs().max()) < 2e-5, c
+
+
+# ---- round-2 additions: goldens that only the CPU oracle used to see, operator-level cover of attn_mid<128>, the
+# ---- diagnostic twin library (fused vs op-by-op), rejected head layouts
+def test_conv_ffn_golden(ops, g, device):
+    """a6: the reference's conv_ffn outputs through the three kernels the forward launches at levels 1-3."""
+    for c, hw in cases.ATTN_CASES:
+        p = dev(params(cases.ffn_spec(c)), device)
+        out = ops.conv_ffn(rnd(f"x.attn{c}", (2, c) + hw).to(device), p["pointwise1.weight"], p["pointwise1.bias"],
+                           p["depthwise.weight"], p["depthwise.bias"], p["pointwise2.weight"], p["pointwise2.bias"])
+        close(out, g[f"conv_ffn_c{c}"])
+
+
+def test_luma_chroma_golden(ops, g, device):
+    """a15: BayerLumaChroma (y normalised by its per-image maximum, cr, cb) against the reference's module."""
+    y, cr, cb = ops.bayer_luma_chroma(rnd("x.packed", (2, 4, 32, 48), 0, 1).to(device))
+    close(torch.cat([y, cr, cb], 1), g["luma_chroma"], 1e-6)
+
+
+@pytest.mark.parametrize("c,heads,hw", [(128, 8, (20, 136)), (128, 8, (8, 8)), (64, 8, (36, 72)), (64, 4, (6, 132))])
+def test_transformer_block_oracle_mid_levels(ops, device, c, heads, hw):
+    """attn_mid_kernel<64|128> on multi-tile shapes that are not multiples of the 4x64 tile (levels 1-2 of the forward)."""
+    spec = cases.transformer_spec(c)
+    spec["attn.temperature"] = (heads, 1, 1)
+    p = params(spec)
+    x = rnd("tb.mid.x", (1, c) + hw)
+    ref = R.transformer_block(x, p, "", heads)
+    close(ops.transformer_block(x.to(device), dev(p, device), heads=heads), ref)
+
+
+def test_transformer_block_ffn_expansion_4(ops, device):
+    """expansion 4 takes the op-by-op FFN whose hidden tensor is 4C wide (scratch sized for it)."""
+    c, heads, hw = 32, 8, (16, 24)
+    spec = cases.transformer_spec(c)
+    spec.update({"ffn.pointwise1.weight": (4 * c, c, 1, 1), "ffn.pointwise1.bias": (4 * c,), "ffn.depthwise.weight": (4 * c, 1, 3, 3),
+                 "ffn.depthwise.bias": (4 * c,), "ffn.pointwise2.weight": (c, 4 * c, 1, 1)})
+    p = params(spec)
+    x = rnd("tb.e4.x", (2, c) + hw)
+    close(ops.transformer_block(x.to(device), dev(p, device), heads=heads, ffn_expansion_factor=4), R.transformer_block(x, p, "", heads))
+
+
+def test_unsupported_head_layout_is_an_error_not_a_wrong_answer(ops, device):
+    c, heads = 40, 1          # head size 40: a query tile would need 5 key tiles
+    p = dev(params(cases.attention_spec(c)), device)
+    with pytest.raises(RuntimeError, match="key tiles"):
+        ops.channel_attention(rnd("x.bad", (1, c, 8, 8)).to(device), p["qkv.weight"], p["qkv.bias"], p["qkv_dwconv.weight"],
+                              p["qkv_dwconv.bias"], p["temperature"][:1], p["project_out.weight"], p["project_out.bias"], heads)
+
+
+def test_fused_kernels_agree_with_the_op_by_op_schedule(device, tmp_path):
+    """The diagnostic twin library (build.py --diag: -DRF_DIAG adds the RF_NO_FUSE / RF_NO_UPCAT switches the shipped
+    library does not have) runs the same block op by op; both schedules must agree to reassociation error."""
+    import os
+    import subprocess
+    import sys
+    from bayer_low_light_image_enhancement_amd import build
+    diag = build.build_diag_library()
+    code = r'''
+import sys, numpy as np, torch
+sys.path.insert(0, sys.argv[1]); sys.path.insert(0, sys.argv[1] + "/tests")
+import cases
+from cases import rnd, params
+from bayer_low_light_image_enhancement_amd import ops, RawFormer, synth
+dev = torch.device("cuda:0")
+outs = {}
+for c, hw in ((32, (20, 72)), (64, (12, 68)), (128, (8, 64))):
+    p = {k: v.to(dev) for k, v in params(cases.transformer_spec(c)).items()}
+    outs[f"tb{c}"] = ops.transformer_block(rnd("tb.x", (2, c) + hw).to(dev), p, heads=8).cpu().numpy()
+m = RawFormer(dim=16)
+m.load_state_dict({**m.state_dict(), **cases.model_state(16, 21)}, strict=True)
+m = m.to(dev).eval()
+with torch.no_grad():
+    outs["model"] = m(torch.from_numpy(synth.bayer_mosaic(21, 2, 64, 64)).to(dev)).cpu().numpy()
+np.savez(sys.argv[2], **outs)
+'''
+    res = {}
+    for tag, env in (("fused", {}), ("plain", {"RF_LIB_PATH": diag, "RF_NO_FUSE": "1", "RF_NO_UPCAT": "1"})):
+        out = str(tmp_path / f"{tag}.npz")
+        e = dict(os.environ)
+        e.pop("RF_LIB_PATH", None)
+        e.update(env)
+        r = subprocess.run([sys.executable, "-c", code, cases.REPO, out], env=e, capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stderr[-3000:]
+        res[tag] = np.load(out)
+    for k in res["fused"].files:
+        close(res["fused"][k], res["plain"][k], 1e-5)
+        assert not np.array_equal(res["fused"][k], res["plain"][k]) or k == "model", f"{k}: the switch changed nothing"

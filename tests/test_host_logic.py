@@ -71,3 +71,39 @@ def test_synthetic_data_is_deterministic():
     assert np.array_equal(u, synth.uniform01(7, "x", 8)[:5]) and not np.array_equal(u, synth.uniform01(8, "x", 5))
     w = synth.param_values(1, "conv_tran1.Conv_out.weight", (32, 32, 3, 3))
     assert abs(float(w.std()) - (1.0 / np.sqrt(32 * 9))) < 2e-3
+
+
+def test_deepcopy_and_pickle_drop_the_runtime_state():
+    """EMA / checkpoint utilities deep-copy and pickle whole modules: handles, workspace and the lock are
+    per-process runtime state and must not travel."""
+    import copy
+    import io
+    m = RawFormer(dim=16)
+    c = copy.deepcopy(m)
+    assert c._rt == {} and c._rt_owner == id(c) and c._rt_lock is not m._rt_lock
+    a, b = dict(m.named_parameters()), dict(c.named_parameters())
+    assert list(a) == list(b) and all(torch.equal(a[k], b[k]) and a[k].data_ptr() != b[k].data_ptr() for k in a)
+    buf = io.BytesIO()
+    torch.save(m, buf)
+    buf.seek(0)
+    r = torch.load(buf, weights_only=False)          # a file this test wrote itself
+    assert r._rt == {} and r._rt_owner == id(r) and set(r.state_dict()) == set(m.state_dict())
+    m.invalidate_packed()                             # no device state yet: a no-op, must not raise
+
+
+def test_unsupported_head_layouts_are_rejected_at_construction():
+    """dim=40 / 8 heads = head size 5..: query tiles would straddle more key tiles than the Gram partial row holds
+    (silently wrong attention before)."""
+    with pytest.raises(RuntimeError, match="key tiles"):
+        RawFormer(dim=40)
+    with pytest.raises(RuntimeError, match="key tiles"):
+        RawFormer(dim=56)
+    RawFormer(dim=24)        # head sizes 3/6/12/24: supported
+
+
+def test_tiles_aligned_to_64_keep_every_level_on_the_vector_paths():
+    from bayer_low_light_image_enhancement_amd import tiling
+    for grid in ((1, 2), (2, 2), (2, 4)):
+        for t in tiling.plan_tiles(2848, 4256, grid, overlap=64, align=64):
+            assert t.src[3] % 64 == 0                 # width: packed/8 = level-3 width is a multiple of 4
+            assert t.src[2] % 16 == 0
