@@ -307,11 +307,11 @@ def test_transformer_block_ffn_expansion_4(ops, device):
 
 
 def test_unsupported_head_layout_is_an_error_not_a_wrong_answer(ops, device):
-    c, heads = 40, 1          # head size 40: a query tile would need 5 key tiles
+    c, heads = 80, 2          # head size 40: the query tile of channels 32..47 straddles both heads = 5 key tiles
     p = dev(params(cases.attention_spec(c)), device)
     with pytest.raises(RuntimeError, match="key tiles"):
         ops.channel_attention(rnd("x.bad", (1, c, 8, 8)).to(device), p["qkv.weight"], p["qkv.bias"], p["qkv_dwconv.weight"],
-                              p["qkv_dwconv.bias"], p["temperature"][:1], p["project_out.weight"], p["project_out.bias"], heads)
+                              p["qkv_dwconv.bias"], p["temperature"][:2].contiguous(), p["project_out.weight"], p["project_out.bias"], heads)
 
 
 def test_fused_kernels_agree_with_the_op_by_op_schedule(device, tmp_path):
