@@ -84,9 +84,13 @@ __device__ __forceinline__ void epilogue(const Conv1x1Args& a, f32x4 (&acc)[NCO]
         }
     } else {
         // ConvTranspose2d(k=2, s=2): GEMM row 4*o + 2*i + jj is output channel o at sub-position
-        // (i, jj); the lane holds the whole 2x2 patch of each of its pixels for channel o.
+        // (i, jj); the lane holds the whole 2x2 patch of each of its pixels for channel o.  The width only has to be
+        // even: pixels (p0, p0+1) and (p0+2, p0+3) are each inside one row (p0 % 4 == 0), so every pixel PAIR is one
+        // aligned 16-byte store per output row (at w = 266, level 3 of a 1424x2128 frame, the two pairs of a lane may
+        // sit in different rows).
         const int w = a.w, w2 = 2 * a.w;
-        const int y = p0 / w, x = p0 - y * w;
+        const int ya = p0 / w, xa = p0 - ya * w;
+        const int yb = (p0 + 2) / w, xb = (p0 + 2) - yb * w;
 #pragma unroll
         for (int t = 0; t < NCO; ++t) {
             if (t >= ntiles) break;
@@ -97,11 +101,10 @@ __device__ __forceinline__ void epilogue(const Conv1x1Args& a, f32x4 (&acc)[NCO]
             if (live && co < a.Cout) {
 #pragma unroll
                 for (int i = 0; i < 2; ++i) {
-                    float* row = op + (size_t)(2 * y + i) * w2 + 2 * x;
-                    *reinterpret_cast<float4*>(row) = make_float4(acc[t][0][2 * i] + bs, acc[t][0][2 * i + 1] + bs,
-                                                                  acc[t][1][2 * i] + bs, acc[t][1][2 * i + 1] + bs);
-                    *reinterpret_cast<float4*>(row + 4) = make_float4(acc[t][2][2 * i] + bs, acc[t][2][2 * i + 1] + bs,
-                                                                      acc[t][3][2 * i] + bs, acc[t][3][2 * i + 1] + bs);
+                    *reinterpret_cast<float4*>(op + (size_t)(2 * ya + i) * w2 + 2 * xa) =
+                        make_float4(acc[t][0][2 * i] + bs, acc[t][0][2 * i + 1] + bs, acc[t][1][2 * i] + bs, acc[t][1][2 * i + 1] + bs);
+                    *reinterpret_cast<float4*>(op + (size_t)(2 * yb + i) * w2 + 2 * xb) =
+                        make_float4(acc[t][2][2 * i] + bs, acc[t][2][2 * i + 1] + bs, acc[t][3][2 * i] + bs, acc[t][3][2 * i + 1] + bs);
                 }
             }
         }
@@ -434,8 +437,8 @@ __global__ void __launch_bounds__(256, 2) conv1x1_stream_kernel(Conv1x1Args a, i
 
 // ---------------------------------------------------------------------------------------------
 // Ragged shapes (P % 4 != 0, unaligned views): one thread per output pixel and channel, plain
-// FMA over K with a two-pass LayerNorm.  Correctness path only: tiny odd test frames, and the
-// ConvTranspose2d scatter (mode 1) when the width is not a multiple of 4.
+// FMA over K with a two-pass LayerNorm.  Correctness path only: tiny odd test frames (a RawFormer level always has
+// an even width and a pixel count divisible by 4 except at 1-2 pixel extents).
 // ---------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(256) conv1x1_scalar_kernel(Conv1x1Args a) {
     const int P = a.P, K = a.C1 + a.C2, NT = (a.Cout + 15) >> 4;
@@ -508,7 +511,7 @@ int launch_conv1x1(const Conv1x1Args& a, hipStream_t st) {
     bool vec = (a.P % 4 == 0) && aligned16(a.x1) && aligned16(a.out) && (a.x1_bstride % 4 == 0) && (a.out_bstride % 4 == 0);
     if (a.x2) vec = vec && aligned16(a.x2) && (a.x2_bstride % 4 == 0);
     if (a.res) vec = vec && aligned16(a.res) && (a.res_bstride % 4 == 0);
-    if (a.mode == 1) vec = vec && (a.w % 4 == 0);
+    if (a.mode == 1) vec = vec && (a.w % 2 == 0);
     const double px = (double)a.B * a.P;
     const double work_flops = 2.0 * K * a.Cout * px, work_bytes = 4.0 * px * (K + a.Cout + (a.res ? a.Cout : 0));
     char key[64];

@@ -473,3 +473,61 @@ def bayer_luma(mosaic: Tensor, pattern: str = "rggb") -> Tensor:
     luma = torch.sum(rgb * torch.tensor([0.299, 0.587, 0.114]).view(1, 3, 1, 1), dim=1, keepdim=True)
     lo, hi = luma.amin(dim=(2, 3), keepdim=True), luma.amax(dim=(2, 3), keepdim=True)
     return (luma - lo) / (hi - lo + 1e-6)
+
+
+# ------------------------------------------------------------------------------------------
+# f2: FFAB / FEB (RawFomer_WFB_FFAB/blocks.py:11-92) and the Mamba-free part of WMB (model.py:203-245)
+# ------------------------------------------------------------------------------------------
+def feb(x: Tensor, p: Dict[str, Tensor], pre: str) -> Tensor:
+    """FEB.forward (blocks.py:23-39): clamp, 1x1, rfft2 (ortho), |.|+1e-6 and angle through two 1x1 MLPs
+    (LeakyReLU 0.1), clamp of the magnitude to [0, 1e4], polar -> cartesian, irfft2 (ortho), + clamped input, clamp."""
+    h, w = x.shape[-2:]
+    x = x.clamp(-10.0, 10.0)
+    f = torch.fft.rfft2(F.conv2d(x, p[pre + "fpre.weight"], p[pre + "fpre.bias"]), norm="ortho")
+    mag, pha = f.abs() + 1e-6, torch.angle(f)
+
+    def mlp(t, name):
+        t = F.leaky_relu(F.conv2d(t, p[pre + name + ".0.weight"], p[pre + name + ".0.bias"]), 0.1)
+        return F.conv2d(t, p[pre + name + ".2.weight"], p[pre + name + ".2.bias"])
+
+    mag = mlp(mag, "process1").clamp(0.0, 1e4)
+    pha = mlp(pha, "process2")
+    out = torch.fft.irfft2(torch.complex(mag * torch.cos(pha), mag * torch.sin(pha)), s=(h, w), norm="ortho")
+    return (out + x).clamp(-10.0, 10.0)
+
+
+def process_block(x: Tensor, p: Dict[str, Tensor], pre: str) -> Tensor:
+    """ProcessBlock.forward (blocks.py:48-55): ``cat(FEB(x)) + x`` with ``cat`` a 1x1 conv."""
+    return F.conv2d(feb(x, p, pre + "frequency_process."), p[pre + "cat.weight"], p[pre + "cat.bias"]) + x
+
+
+def ffab(x: Tensor, p: Dict[str, Tensor], pre: str) -> Tensor:
+    """FFAB.forward (blocks.py:83-92): seven ProcessBlocks with dense concatenations."""
+    x = process_block(F.conv2d(x, p[pre + "conv0.0.weight"], p[pre + "conv0.0.bias"]), p, pre + "conv0.1.")
+    x1 = process_block(x, p, pre + "conv1.")
+    x2 = process_block(x1, p, pre + "conv2.")
+    x3 = process_block(x2, p, pre + "conv3.")
+
+    def tail(a, b, name):
+        t = process_block(torch.cat((a, b), dim=1), p, pre + name + ".0.")
+        return F.conv2d(t, p[pre + name + ".1.weight"], p[pre + name + ".1.bias"])
+
+    x4 = tail(x2, x3, "conv4")
+    x5 = tail(x1, x4, "conv5")
+    return tail(x, x5, "convout")
+
+
+def wmb_ll_branch(x: Tensor, p: Dict[str, Tensor], pre: str, high=None) -> Tensor:
+    """WMB.forward (RawFomer_WFB_FFAB/model.py:215-245) up to and including the residual of the wavelet branch, with the
+    Mamba module ``mb`` (absent offline: ``mamba_ssm``, parity unpinned) replaced by ``high`` (a callable on the
+    ``[3B,C,h/2,w/2]`` high bands; identity when ``None``):
+    ``t = 2 LN(x) - 1;  LL, high = DWT(t);  LL = FFAB(illu(LL));  out = t + clamp((IWT(cat(LL, high(high))) + 1) / 2, 0, 1)``."""
+    n = x.shape[0]
+    t = 2.0 * layernorm2d(x, p[pre + "norm1.body.weight"], p[pre + "norm1.body.bias"]) - 1.0
+    d = dwt_init(t)
+    ll, hi = d[:n], d[n:]
+    ll, _ = illumination_estimator(ll, p, pre + "illu.")
+    ll = ffab(ll, p, pre + "ffab.")
+    if high is not None:
+        hi = high(hi)
+    return t + ((iwt_init(torch.cat((ll, hi), dim=0)) + 1.0) / 2.0).clamp(0.0, 1.0)
