@@ -16,10 +16,10 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(CSRC, "librawformer_hip.so")
 # Test-only twin of the library: the two host schedules recompiled with -DRF_DIAG, which adds the environment switches
-# RF_NO_FUSE / RF_NO_UPCAT (force the op-by-op schedule) so tests can compare the fused kernels with the un-fused chain.
+# RF_NO_FUSE / RF_NO_UPCAT / RF_NO_B3 (force the op-by-op schedule / the f32 MFMA GEMMs) so tests can compare the fused kernels with the un-fused chain.
 # The shipped library has no such switch.  Selected with RF_LIB_PATH (see _lib.py).
 DIAG_LIB = os.path.join(CSRC, "librawformer_hip_diag.so")
-DIAG_SOURCES = ["rf_block.hip", "rf_model.hip"]
+DIAG_SOURCES = ["rf_block.hip", "rf_model.hip", "rf_gemm1x1.hip"]
 SOURCES = ["rf_api.hip", "rf_model.hip", "rf_pack.hip", "rf_pointwise.hip", "rf_gemm1x1.hip",
            "rf_conv3x3.hip", "rf_attn.hip", "rf_flca.hip", "rf_fused.hip", "rf_block.hip", "rf_harness.hip", "rf_tokattn.hip", "rf_wfb.hip", "rf_upcat.hip"]
 FLAGS = ["-O3", "-std=c++17", "-fPIC", "--offload-arch=gfx950", "-Wall", "-Wno-unused-function"]

@@ -159,7 +159,7 @@ int rf_layernorm2d(const float* in, float* out, const float* weight, const float
 
 int rf_conv1x1_scratch_bytes(int Cin_total, int Cout, size_t* bytes) {
     RF_CHECK_ARG(bytes && Cin_total > 0 && Cout > 0, "conv1x1_scratch_bytes: bad arguments");
-    *bytes = packed1x1_floats(Cin_total, Cout) * sizeof(float);
+    *bytes = (align_up(packed1x1_floats(Cin_total, Cout), 64) + packed1x1_b3_floats(Cin_total, Cout)) * sizeof(float);
     return RF_OK;
 }
 
@@ -170,10 +170,12 @@ int rf_conv1x1(const float* in, const float* in2, float* out, const float* weigh
     hipStream_t st = (hipStream_t)stream;
     const int K = C1 + C2;
     RF_TRY(pack_1x1(weight, (float*)scratch, Cout, K, K, 1, st));
+    float* w3 = (float*)scratch + align_up(packed1x1_floats(K, Cout), 64);
+    RF_TRY(pack_1x1_b3(weight, w3, Cout, K, K, 1, st));
     Conv1x1Args a{};
     a.x1 = in; a.C1 = C1; a.x1_bstride = (int64_t)C1 * h * w;
     a.x2 = C2 ? in2 : nullptr; a.C2 = C2; a.x2_bstride = (int64_t)C2 * h * w;
-    a.wp = (const float*)scratch; a.bias = bias; a.ln_w = ln_w; a.ln_b = ln_b; a.ln_eps = 1e-5f;
+    a.wp = (const float*)scratch; a.wp3 = w3; a.bias = bias; a.ln_w = ln_w; a.ln_b = ln_b; a.ln_eps = 1e-5f;
     a.res = res; a.res_bstride = (int64_t)Cout * h * w;
     a.out = out; a.out_bstride = (int64_t)Cout * h * w; a.Cout = Cout; a.B = B; a.P = h * w; a.w = w;
     return launch_conv1x1(a, st);
@@ -225,7 +227,7 @@ int rf_convT2x2(const float* in, float* out, const float* weight, const float* b
 
 // scratch layout of rf_chan_attn: packed qkv weights | qkv_pre | qkv | gram partials | folded weights
 struct AttnScratch {
-    size_t wqkv, pre, qkv, partial, wfold, total;
+    size_t wqkv, wqkv3, pre, qkv, partial, wfold, wfold3, total;
 };
 static int attn_scratch(int B, int C, int heads, int h, int w, AttnScratch* s) {
     const int P = h * w;
@@ -240,10 +242,12 @@ static int attn_scratch(int B, int C, int heads, int h, int w, AttnScratch* s) {
     size_t off = 0;
     auto take = [&](size_t f) { const size_t o = off; off += align_up(f, 64); return o; };
     s->wqkv = take(packed1x1_floats(C, 3 * C));
+    s->wqkv3 = take(packed1x1_b3_floats(C, 3 * C));
     s->pre = take((size_t)B * 3 * C * P);
     s->qkv = take((size_t)B * 3 * C * P);
     s->partial = take(pf);
     s->wfold = take((size_t)B * packed1x1_floats(C, C));
+    s->wfold3 = take((size_t)B * packed1x1_b3_floats(C, C));
     s->total = off;
     return RF_OK;
 }
@@ -267,8 +271,9 @@ int rf_chan_attn(const float* in, float* out, const float* qkv_w, const float* q
     RF_TRY(attn_scratch(B, C, heads, h, w, &s));
     float* ws = (float*)scratch;
     RF_TRY(pack_1x1(qkv_w, ws + s.wqkv, 3 * C, C, C, 1, st));
+    RF_TRY(pack_1x1_b3(qkv_w, ws + s.wqkv3, 3 * C, C, C, 1, st));
     Conv1x1Args q{};
-    q.x1 = in; q.C1 = C; q.x1_bstride = (int64_t)C * P; q.wp = ws + s.wqkv; q.bias = qkv_b;
+    q.x1 = in; q.C1 = C; q.x1_bstride = (int64_t)C * P; q.wp = ws + s.wqkv; q.wp3 = ws + s.wqkv3; q.bias = qkv_b;
     q.out = ws + s.pre; q.out_bstride = (int64_t)3 * C * P; q.Cout = 3 * C; q.B = B; q.P = P; q.w = w;
     RF_TRY(launch_conv1x1(q, st));
     Conv1x1Args av{};
@@ -293,21 +298,25 @@ int rf_chan_attn(const float* in, float* out, const float* qkv_w, const float* q
         nslab = g.nslab;
         av.x1 = ws + s.qkv + (size_t)2 * C * P; av.x1_bstride = (int64_t)3 * C * P;
     }
-    RF_TRY(launch_attn_fold(ws + s.partial, nslab, temperature, proj_w, ws + s.wfold, B, C, heads, st));
+    RF_TRY(launch_attn_fold(ws + s.partial, nslab, temperature, proj_w, ws + s.wfold, ws + s.wfold3, B, C, heads, st));
     av.C1 = C;
     av.wp = ws + s.wfold; av.wp_bstride = (int64_t)packed1x1_floats(C, C); av.bias = proj_b;
+    av.wp3 = ws + s.wfold3; av.wp3_bstride = (int64_t)packed1x1_b3_floats(C, C);
     av.out = out; av.out_bstride = (int64_t)C * P; av.Cout = C; av.B = B; av.P = P; av.w = w;
     return launch_conv1x1(av, st);
 }
 
 // scratch layout of rf_transformer_block: packed qkv | packed pw1 | packed pw2 | run_transformer buffers
-struct TbScratch { size_t wqkv, w1, w2, bufs, total; TbBufOffsets o; };
+struct TbScratch { size_t wqkv, w1, w2, wqkv3, w13, w23, bufs, total; TbBufOffsets o; };
 static void tb_scratch(int B, int C, int heads, int hc, int h, int w, TbScratch* s) {
     size_t off = 0;
     auto take = [&](size_t f) { const size_t r = off; off += align_up(f, 64); return r; };
     s->wqkv = take(packed1x1_floats(C, 3 * C));
     s->w1 = take(packed1x1_floats(C, hc));
     s->w2 = take(packed1x1_floats(hc, C));
+    s->wqkv3 = take(packed1x1_b3_floats(C, 3 * C));
+    s->w13 = take(packed1x1_b3_floats(C, hc));
+    s->w23 = take(packed1x1_b3_floats(hc, C));
     s->bufs = off;
     s->total = off + transformer_scratch_floats(B, C, heads, hc, h, w, &s->o);
 }
@@ -337,8 +346,12 @@ int rf_transformer_block(const float* in, float* out, const float* const* prm, v
     RF_TRY(pack_1x1(prm[3], ws + s.wqkv, 3 * C, C, C, 1, st));
     RF_TRY(pack_1x1(prm[11], ws + s.w1, hc, C, C, 1, st));
     RF_TRY(pack_1x1(prm[15], ws + s.w2, C, hc, hc, 1, st));
+    RF_TRY(pack_1x1_b3(prm[3], ws + s.wqkv3, 3 * C, C, C, 1, st));
+    RF_TRY(pack_1x1_b3(prm[11], ws + s.w13, hc, C, C, 1, st));
+    RF_TRY(pack_1x1_b3(prm[15], ws + s.w23, C, hc, hc, 1, st));
     TbParams p{prm[0], prm[1], prm[2], ws + s.wqkv, prm[4], prm[5], prm[6], prm[7], prm[8],
-               prm[9], prm[10], ws + s.w1, prm[12], prm[13], prm[14], ws + s.w2, prm[16]};
+               prm[9], prm[10], ws + s.w1, prm[12], prm[13], prm[14], ws + s.w2, prm[16],
+               ws + s.wqkv3, ws + s.w13, ws + s.w23};
     return run_transformer(p, in, out, ws + s.bufs, s.o, B, C, heads, hc, h, w, st);
 }
 

@@ -178,7 +178,7 @@ int launch_gram(const GramArgs& a, hipStream_t st) {
 __global__ void __launch_bounds__(256) attn_fold_kernel(const float* __restrict__ partial, int nslab,
                                                         const float* __restrict__ temperature,
                                                         const float* __restrict__ w_out, float* __restrict__ wp_out,
-                                                        int C, int heads) {
+                                                        unsigned short* __restrict__ wp3_out, int C, int heads) {
     const int hd = blockIdx.x, b = blockIdx.y;
     const int c = C / heads;
     const int NT = (C + 15) >> 4;
@@ -257,6 +257,8 @@ __global__ void __launch_bounds__(256) attn_fold_kernel(const float* __restrict_
     __syncthreads();
     // 3. W'[co][hd*c + j] = sum_i W_out[co][hd*c + i] * attn[i][j], stored in MFMA operand order
     float* dst = wp_out + (size_t)b * NT * (C / 4) * 64;
+    const int NB = (C + 31) >> 5;
+    unsigned short* dst3 = wp3_out ? wp3_out + (size_t)b * NT * NB * 1536 : nullptr;   // b3 form of the same matrix (rf_common.h)
     for (int idx = threadIdx.x; idx < NT * 16 * c; idx += 256) {
         const int co = idx / c, jj = idx % c;
         float s = 0.f;
@@ -266,14 +268,19 @@ __global__ void __launch_bounds__(256) attn_fold_kernel(const float* __restrict_
         }
         const int k = hd * c + jj;
         dst[((size_t)(k >> 2) * NT + (co >> 4)) * 64 + (co & 15) + 16 * (k & 3)] = s;
+        if (dst3) b3_store(dst3, NT, co, k, s);
     }
+    // columns C .. 32 NB - 1 of the padded b3 matrix (C not a multiple of 32): zero, written by the last head's workgroup
+    if (dst3 && hd == heads - 1)
+        for (int idx = threadIdx.x; idx < NT * 16 * (32 * NB - C); idx += 256)
+            b3_store(dst3, NT, idx / (32 * NB - C), C + idx % (32 * NB - C), 0.f);
 }
 
 int launch_attn_fold(const float* partial, int nslab, const float* temperature, const float* w_out,
-                     float* wp_out, int B, int C, int heads, hipStream_t st) {
+                     float* wp_out, void* wp3_out, int B, int C, int heads, hipStream_t st) {
     RF_CHECK_ARG(C % heads == 0 && C / heads <= 64 && C % 4 == 0, "attn_fold: unsupported C=%d heads=%d", C, heads);
     ProfScope prof(st, "attn_fold_kernel", 0.0, 0.0);
-    attn_fold_kernel<<<dim3((unsigned)heads, (unsigned)B), 256, 0, st>>>(partial, nslab, temperature, w_out, wp_out, C, heads);
+    attn_fold_kernel<<<dim3((unsigned)heads, (unsigned)B), 256, 0, st>>>(partial, nslab, temperature, w_out, wp_out, (unsigned short*)wp3_out, C, heads);
     return check_launch("attn_fold");
 }
 

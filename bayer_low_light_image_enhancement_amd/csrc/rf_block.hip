@@ -27,6 +27,7 @@ size_t transformer_scratch_floats(int B, int C, int heads, int hc, int h, int w,
     if (attn_mid_supported(C, heads, h, w)) attn_mid_plan(h, w, &ns, &pf2, B, C);
     o->partial = take(pf > pf2 ? pf : pf2);
     o->wfold = take((size_t)B * packed1x1_floats(C, C));
+    o->wfold3 = take((size_t)B * packed1x1_b3_floats(C, C));
     return off;
 }
 
@@ -38,16 +39,18 @@ int run_transformer(const TbParams& p, const float* in, float* out, float* ws, c
     float* x1 = ws + o.x1;
     float* partial = ws + o.partial;
     float* wfold = ws + o.wfold;
+    float* wfold3 = ws + o.wfold3;
 #ifdef RF_DIAG   // diagnostic build only (build.py --diag): force the op-by-op path; the shipped library has no switch
     const bool no_fuse = getenv("RF_NO_FUSE") != nullptr;
+    const bool no_fuse_attn = no_fuse || getenv("RF_NO_FUSE_ATTN") != nullptr, no_fuse_ffn = no_fuse || getenv("RF_NO_FUSE_FFN") != nullptr;
 #else
-    constexpr bool no_fuse = false;
+    constexpr bool no_fuse = false, no_fuse_attn = false, no_fuse_ffn = false;
 #endif
 
     // x + attn(LN1(x)) ---------------------------------------------------------------------
     Conv1x1Args av{};
     int nslab = 0;
-    if (!no_fuse && fused_attn_supported(C, heads, hh, ww)) {
+    if (!no_fuse_attn && fused_attn_supported(C, heads, hh, ww)) {
         // LN1 -> qkv 1x1 -> depthwise 3x3 -> {Gram partials, v} in one kernel: qkv never reaches HBM
         size_t pf;
         RF_TRY(fused_attn_plan(hh, ww, &nslab, &pf, B, C));
@@ -56,7 +59,7 @@ int run_transformer(const TbParams& p, const float* in, float* out, float* ws, c
     } else {
         Conv1x1Args q{};
         q.x1 = in; q.C1 = C; q.x1_bstride = (int64_t)C * Pn;
-        q.wp = p.qkv_wp; q.bias = p.qkv_b;
+        q.wp = p.qkv_wp; q.wp3 = p.qkv_wp3; q.bias = p.qkv_b;
         q.ln_w = p.ln1_w; q.ln_b = p.ln1_b; q.ln_eps = 1e-5f;
         q.out = bufA; q.out_bstride = (int64_t)3 * C * Pn; q.Cout = 3 * C; q.B = B; q.P = Pn; q.w = ww;
         RF_TRY(launch_conv1x1(q, st));
@@ -84,22 +87,23 @@ int run_transformer(const TbParams& p, const float* in, float* out, float* ws, c
         av.x1 = bufB + (size_t)2 * C * Pn; av.x1_bstride = (int64_t)3 * C * Pn;
         }
     }
-    RF_TRY(launch_attn_fold(partial, nslab, p.temperature, p.proj_w, wfold, B, C, heads, st));
+    RF_TRY(launch_attn_fold(partial, nslab, p.temperature, p.proj_w, wfold, wfold3, B, C, heads, st));
     av.C1 = C;
     av.wp = wfold; av.wp_bstride = (int64_t)packed1x1_floats(C, C);
+    av.wp3 = wfold3; av.wp3_bstride = (int64_t)packed1x1_b3_floats(C, C);
     av.bias = p.proj_b;
     av.res = in; av.res_bstride = (int64_t)C * Pn;
     av.out = x1; av.out_bstride = (int64_t)C * Pn; av.Cout = C; av.B = B; av.P = Pn; av.w = ww;
     RF_TRY(launch_conv1x1(av, st));
 
     // x + ffn(LN2(x)) ----------------------------------------------------------------------
-    if (!no_fuse && fused_ffn_supported(C, hc, hh, ww)) {
+    if (!no_fuse_ffn && fused_ffn_supported(C, hc, hh, ww)) {
         // LN2 -> 1x1 -> depthwise 3x3 -> GELU -> 1x1 + residual in one kernel: the hidden tensor stays on chip
         RF_TRY(launch_ffn_fused(x1, out, p.ln2_w, p.ln2_b, p.pw1_wp, p.pw1_b, p.dw_w, p.dw_b, p.pw2_wp, p.pw2_b, B, C, hh, ww, st));
     } else {
         Conv1x1Args f1{};
         f1.x1 = x1; f1.C1 = C; f1.x1_bstride = (int64_t)C * Pn;
-        f1.wp = p.pw1_wp; f1.bias = p.pw1_b;
+        f1.wp = p.pw1_wp; f1.wp3 = p.pw1_wp3; f1.bias = p.pw1_b;
         f1.ln_w = p.ln2_w; f1.ln_b = p.ln2_b; f1.ln_eps = 1e-5f;
         f1.out = bufA; f1.out_bstride = (int64_t)hc * Pn; f1.Cout = hc; f1.B = B; f1.P = Pn; f1.w = ww;
         RF_TRY(launch_conv1x1(f1, st));
@@ -112,7 +116,7 @@ int run_transformer(const TbParams& p, const float* in, float* out, float* ws, c
 
         Conv1x1Args f2{};
         f2.x1 = bufB; f2.C1 = hc; f2.x1_bstride = (int64_t)hc * Pn;
-        f2.wp = p.pw2_wp; f2.bias = p.pw2_b;
+        f2.wp = p.pw2_wp; f2.wp3 = p.pw2_wp3; f2.bias = p.pw2_b;
         f2.res = x1; f2.res_bstride = (int64_t)C * Pn;
         f2.out = out; f2.out_bstride = (int64_t)C * Pn; f2.Cout = C; f2.B = B; f2.P = Pn; f2.w = ww;
         RF_TRY(launch_conv1x1(f2, st));

@@ -68,6 +68,60 @@ static inline size_t packed1x1_floats(int K, int Cout) { return (size_t)cdiv(K, 
 // 3x3 weights are packed in Winograd F(4,3) form along x: 18 transformed taps per k-set
 static inline size_t packed3x3_floats(int Cin, int Cout) { return (size_t)cdiv(Cin, 8) * 2 * 18 * cdiv(Cout, 16) * 64; }
 
+// ---------------------------------------------------------------------------------------------
+// "b3" operands: an f32 value as the exact sum of three bf16 pieces (truncation split: x = p0 + p1 + p2, 8 significant
+// bits each), contracted on the bf16 matrix pipe as six cross terms with f32 accumulation
+//   a b ~= a2 b0 + a0 b2 + a1 b1 + a1 b0 + a0 b1 + a0 b0        (dropped: a1 b2, a2 b1, a2 b2 <= 2^-24 |a b|)
+// Measured on MI355X (tools/ubench/bf16x3.hip, profiles/r02_ubench_*.txt): the error against an f64 reference equals
+// the f32 MFMA chain's (7e-8 .. 6e-7 of sum |a b|, K = 32 .. 2304), and v_mfma_f32_16x16x32_bf16 issues every 17 cycles
+// for K = 32 where v_mfma_f32_16x16x4_f32 needs 8 x 33: 6 x 17 = 102 cycles per 16x16x32 block instead of 264.
+// (The f32 MFMA runs at the f32 VECTOR rate and is mutually exclusive with VALU work on its SIMD -- tools/ubench/
+// mfma_valu.hip -- so it buys operand reuse, not throughput.)
+//   v_mfma_f32_16x16x32_bf16:  A lane l holds A[i = l & 15][k = 8 (l >> 4) + e], e = 0..7 (16 bytes, e = ushort index)
+//                              B lane l holds B[k = 8 (l >> 4) + e][j = l & 15];   C/D as for the f32 instruction
+// A packed b3 weight matrix [Cout][K]: per (k-block s32 of 32 channels, output tile t of 16) three 1 KiB pieces
+//   packed3[(((s32 * NT + t) * 3 + piece) * 64 + l) * 8 + e] = piece(W[16 t + (l & 15)][32 s32 + 8 (l >> 4) + e])   (ushort)
+// ---------------------------------------------------------------------------------------------
+static inline size_t packed1x1_b3_floats(int K, int Cout) { return (size_t)cdiv(K, 32) * cdiv(Cout, 16) * 768; }
+int pack_1x1_b3(const float* w, void* packed3, int Cout, int K, int64_t row_stride, int64_t col_stride, hipStream_t st);
+// device helpers shared by every producer / consumer of b3 operands
+#ifdef __HIPCC__
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+__device__ __forceinline__ void b3_split(float x, unsigned& p0, unsigned& p1, unsigned& p2) {   // pieces = HIGH halves of p0, p1, p2
+    p0 = __float_as_uint(x);
+    const float r1 = x - __uint_as_float(p0 & 0xffff0000u);
+    p1 = __float_as_uint(r1);
+    p2 = __float_as_uint(r1 - __uint_as_float(p1 & 0xffff0000u));
+}
+__device__ __forceinline__ unsigned b3_pack(unsigned even_elem, unsigned odd_elem) {   // high halves -> one dword (element e at ushort e)
+    return __builtin_amdgcn_perm(odd_elem, even_elem, 0x07060302u);
+}
+__device__ __forceinline__ size_t b3_index(int NT, int co, int k, int piece) {   // ushort index of W[co][k]'s piece
+    const int lane = (co & 15) + 16 * ((k & 31) >> 3);
+    return ((((size_t)(k >> 5) * NT + (co >> 4)) * 3 + piece) * 64 + lane) * 8 + (k & 7);
+}
+__device__ __forceinline__ void b3_store(unsigned short* dst, int NT, int co, int k, float v) {
+    unsigned p0, p1, p2;
+    b3_split(v, p0, p1, p2);
+    dst[b3_index(NT, co, k, 0)] = (unsigned short)(p0 >> 16);
+    dst[b3_index(NT, co, k, 1)] = (unsigned short)(p1 >> 16);
+    dst[b3_index(NT, co, k, 2)] = (unsigned short)(p2 >> 16);
+}
+// six cross terms, smallest first
+__device__ __forceinline__ f32x4 b3_mfma(const u32x4 (&a)[3], const u32x4 (&b)[3], f32x4 c) {
+#define RF_B3(x) __builtin_bit_cast(bf16x8, x)
+    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(RF_B3(a[2]), RF_B3(b[0]), c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(RF_B3(a[0]), RF_B3(b[2]), c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(RF_B3(a[1]), RF_B3(b[1]), c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(RF_B3(a[1]), RF_B3(b[0]), c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(RF_B3(a[0]), RF_B3(b[1]), c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(RF_B3(a[0]), RF_B3(b[0]), c, 0, 0, 0);
+#undef RF_B3
+    return c;
+}
+#endif
+
 // ---- weight repacking (rf_pack.hip)
 // 1x1: W[Cout][K] row-major -> packed.  `row_stride`/`col_stride` let the source be a
 // ConvTranspose2d weight [Cin][Cout][2][2] viewed as rows (o,i,j) x cols k.
@@ -90,6 +144,8 @@ struct Conv1x1Args {
     int64_t x2_bstride;
     const float* wp;       // packed weights
     int64_t wp_bstride;    // floats between per-image weight sets (0 = shared)
+    const void* wp3;       // the same weights in b3 form (packed1x1_b3_floats) or nullptr: selects the bf16x3 kernels
+    int64_t wp3_bstride;   // floats between per-image b3 weight sets (0 = shared)
     const float* bias;     // [Cout] or nullptr
     const float* ln_w;     // LayerNorm prologue over the K channels (nullptr = none)
     const float* ln_b;
@@ -157,7 +213,7 @@ int gram_plan(int B, int C, int heads, int P, int* nslab, int* slab, size_t* par
 int launch_gram(const GramArgs& a, hipStream_t st);
 // softmax + fold into project_out: wp_out[b] = pack(W_out * blockdiag(attn_b))
 int launch_attn_fold(const float* partial, int nslab, const float* temperature, const float* w_out,
-                     float* wp_out, int B, int C, int heads, hipStream_t st);
+                     float* wp_out, void* wp3_out /* b3 form too, or nullptr */, int B, int C, int heads, hipStream_t st);
 
 // ---- fused transformer-block kernels for C = 32 / 64 (rf_fused.hip)
 bool fused_ffn_supported(int C, int hidden, int h, int w);
@@ -179,8 +235,9 @@ struct TbParams {
     const float *ln1_w, *ln1_b, *temperature;
     const float *qkv_wp /* packed */, *qkv_b, *qkv_dw_w, *qkv_dw_b, *proj_w /* raw [C][C] */, *proj_b;
     const float *ln2_w, *ln2_b, *pw1_wp /* packed */, *pw1_b, *dw_w, *dw_b, *pw2_wp /* packed */, *pw2_b;
+    const void *qkv_wp3, *pw1_wp3, *pw2_wp3;   // b3 forms of the three packed weights (nullptr: f32 kernels only)
 };
-struct TbBufOffsets { size_t bufA, bufB, x1, partial, wfold; };   // float offsets into one scratch area
+struct TbBufOffsets { size_t bufA, bufB, x1, partial, wfold, wfold3; };   // float offsets into one scratch area
 size_t transformer_scratch_floats(int B, int C, int heads, int hc, int h, int w, TbBufOffsets* o);
 int run_transformer(const TbParams& p, const float* in, float* out, float* ws, const TbBufOffsets& o,
                     int B, int C, int heads, int hc, int hh, int ww, hipStream_t st);
@@ -207,6 +264,6 @@ int launch_scale_channels(float* x, const float* ch, int B, int C, int P, hipStr
 // SE + fold into channel_reduce: wp_out[b] = pack([Wa * diag(ch_b) | Wb])
 int launch_flca_se_fold(const float* partial, int nblk, int P, const float* se1_w, const float* se1_b,
                         const float* se3_w, const float* se3_b, int hidden, const float* w_cr,
-                        float* wp_out, float* ch_out, int B, int C, hipStream_t st);
+                        float* wp_out, void* wp3_out /* b3 form too, or nullptr */, float* ch_out, int B, int C, hipStream_t st);
 
 }  // namespace rf

@@ -350,17 +350,20 @@ __global__ void __launch_bounds__(256) flca_se_kernel(const float* __restrict__ 
 }
 
 // wp_out[b] = pack([W_a diag(ch_b) | W_b]) in MFMA operand order
+// (and, when wp3_out is given, the same matrix in b3 form for the bf16x3 GEMM: rf_common.h)
 __global__ void __launch_bounds__(256) flca_fold_kernel(const float* __restrict__ w_cr, const float* __restrict__ ch,
-                                                        float* __restrict__ wp_out, int C) {
+                                                        float* __restrict__ wp_out, unsigned short* __restrict__ wp3_out, int C) {
     const size_t b = blockIdx.y;
-    const int NT = (C + 15) >> 4, NS = (2 * C) >> 2;
+    const int NT = (C + 15) >> 4, NS = (2 * C) >> 2, NB = (2 * C + 31) >> 5;
     float* dst = wp_out + b * (size_t)NT * NS * 64;
-    for (int idx = blockIdx.x * 256 + threadIdx.x; idx < NT * NS * 64; idx += gridDim.x * 256) {
-        const int l = idx & 63, t = (idx >> 6) % NT, s = (idx >> 6) / NT;
+    unsigned short* dst3 = wp3_out ? wp3_out + b * (size_t)NT * NB * 1536 : nullptr;
+    for (int idx = blockIdx.x * 256 + threadIdx.x; idx < NT * NB * 512; idx += gridDim.x * 256) {
+        const int l = idx & 63, t = (idx >> 6) % NT, s = (idx >> 6) / NT;      // s runs over the 8 NB k-sets of the padded matrix
         const int co = 16 * t + (l & 15), k = 4 * s + (l >> 4);
         float v = 0.f;
-        if (co < C) v = w_cr[(size_t)co * 2 * C + k] * (k < C ? ch[b * C + k] : 1.0f);
-        dst[idx] = v;
+        if (co < C && k < 2 * C) v = w_cr[(size_t)co * 2 * C + k] * (k < C ? ch[b * C + k] : 1.0f);
+        if (s < NS) dst[((size_t)s * NT + t) * 64 + l] = v;
+        if (dst3) b3_store(dst3, NT, co, k, v);
     }
 }
 
@@ -385,13 +388,13 @@ int launch_scale_channels(float* x, const float* ch, int B, int C, int P, hipStr
 
 int launch_flca_se_fold(const float* partial, int nblk, int P, const float* se1_w, const float* se1_b,
                         const float* se3_w, const float* se3_b, int hidden, const float* w_cr,
-                        float* wp_out, float* ch_out, int B, int C, hipStream_t st) {
+                        float* wp_out, void* wp3_out, float* ch_out, int B, int C, hipStream_t st) {
     ProfScope prof(st, "flca_se_kernel+flca_fold_kernel", 0.0, 0.0);
     const int rc = launch_flca_se(partial, nblk, P, se1_w, se1_b, se3_w, se3_b, hidden, ch_out, B, C, st);
     if (rc) return rc;
-    int gx = cdiv(cdiv(C, 16) * (C / 2) * 64, 256 * 4);
+    int gx = cdiv(cdiv(C, 16) * cdiv(2 * C, 32) * 512, 256 * 4);
     if (gx < 1) gx = 1;
-    flca_fold_kernel<<<dim3((unsigned)gx, (unsigned)B), 256, 0, st>>>(w_cr, ch_out, wp_out, C);
+    flca_fold_kernel<<<dim3((unsigned)gx, (unsigned)B), 256, 0, st>>>(w_cr, ch_out, wp_out, (unsigned short*)wp3_out, C);
     return check_launch("flca_se_fold");
 }
 

@@ -435,6 +435,171 @@ __global__ void __launch_bounds__(256, 2) conv1x1_stream_kernel(Conv1x1Args a, i
     epilogue<NCO, false>(a, acc, t0, tcnt, bias_l, nullptr, b, p0, kq, live);
 }
 
+
+// ---------------------------------------------------------------------------------------------
+// b3 streaming kernel: the same GEMM on the bf16 matrix pipe with three-piece operands (rf_common.h).
+// K is streamed in blocks of 32 channels = one v_mfma_f32_16x16x32_bf16 K extent.  Lane (j, kq) loads, for i = 0..7,
+// one float4 = pixels p0 + 4j .. 4j+3 of channel 32c + 8kq + i; component g of those eight registers is -- after the
+// split -- the B operand of pixel group g (the D layout, and with it the epilogue, is that of the f32 kernels).
+// Per block and wave: 176 VALU for the split of 32 values x 4 pixels, 3 * NCO ds_read_b128 for the weight pieces,
+// 24 * NCO MFMAs of 17 cycles (f32 form: 32 * NCO MFMAs of 33 cycles).  The next block's x is loaded into the registers
+// the split has just vacated, its weights go registers -> LDS behind the MFMAs; one barrier per block.
+// ---------------------------------------------------------------------------------------------
+template <int NCO, bool LN>
+__global__ void __launch_bounds__(256, 2) conv1x1_b3_kernel(Conv1x1Args a, int ngroups) {
+    __shared__ __attribute__((aligned(16))) u32x4 lds_w[2][NCO * 3 * 64];
+    __shared__ float bias_l[NCO * 16];
+    __shared__ float gam_l[LN ? kStreamLnMaxK : 4], bet_l[LN ? kStreamLnMaxK : 4];
+    constexpr int WPT = (NCO * 3 * 64 + 255) / 256;   // 16-byte weight elements each thread moves per block
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int j = lane & 15, kq = lane >> 4;
+    const int grp = blockIdx.x % ngroups;
+    const int tile = blockIdx.x / ngroups;
+    const int b = blockIdx.y;
+    const int P = a.P;
+    const int K = a.C1 + a.C2;
+    const int NB = (K + 31) >> 5;
+    const int NT = (a.Cout + 15) >> 4;
+    const int t0 = grp * NCO;
+    const int tcnt = (NT - t0 < NCO) ? NT - t0 : NCO;
+    const int p0 = (tile * 4 + wave) * 64 + 4 * j;
+    const bool live = p0 < P;
+    const unsigned pl = (unsigned)(live ? p0 : 0);
+    const u32x4* wp3 = reinterpret_cast<const u32x4*>(reinterpret_cast<const float*>(a.wp3) + (size_t)b * a.wp3_bstride);
+    stage_bias(a, bias_l, t0, NCO, tid);
+    if constexpr (LN) {
+        for (int i = tid; i < 32 * NB; i += 256) {
+            gam_l[i] = i < K ? a.ln_w[i] : 0.f;
+            bet_l[i] = (a.ln_b && i < K) ? a.ln_b[i] : 0.f;
+        }
+    }
+
+    f32x4 acc[NCO][4];
+#pragma unroll
+    for (int t = 0; t < NCO; ++t)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) acc[t][g] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    if (a.res && a.mode == 0) {   // the residual initialises the accumulators (branch-free loads, see conv1x1_stream_kernel)
+        const float* resb = a.res + (size_t)b * a.res_bstride;
+#pragma unroll
+        for (int t = 0; t < NCO; ++t)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int co = 16 * (t0 + t) + 4 * kq + r;
+                const bool ok = live && t < tcnt && co < a.Cout;
+                const float4 rv = ldv(resb + (size_t)(ok ? co : 0) * P, pl);
+                acc[t][0][r] = ok ? rv.x : 0.f; acc[t][1][r] = ok ? rv.y : 0.f;
+                acc[t][2][r] = ok ? rv.z : 0.f; acc[t][3][r] = ok ? rv.w : 0.f;
+            }
+    }
+
+    // LayerNorm statistics (shifted single pass; lanes kq = 0..3 split the channels)
+    float lnA[4] = {1.f, 1.f, 1.f, 1.f}, lnB[4] = {0.f, 0.f, 0.f, 0.f};
+    if constexpr (LN) {
+        const unsigned voff = (unsigned)kq * (unsigned)P + pl;
+        const float4 s4 = ldv(kset_base(a, b, 0), pl);
+        const float sh[4] = {s4.x, s4.y, s4.z, s4.w};
+        float s1[4] = {0.f, 0.f, 0.f, 0.f}, s2[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll 16
+        for (int s = 0; s < (K >> 2); ++s) {
+            const float4 t = ldv(kset_base(a, b, s), voff);
+            const float d[4] = {t.x - sh[0], t.y - sh[1], t.z - sh[2], t.w - sh[3]};
+#pragma unroll
+            for (int g = 0; g < 4; ++g) { s1[g] += d[g]; s2[g] = fmaf(d[g], d[g], s2[g]); }
+        }
+        const float invK = 1.0f / (float)K;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            s1[g] += __shfl_xor(s1[g], 16); s1[g] += __shfl_xor(s1[g], 32);
+            s2[g] += __shfl_xor(s2[g], 16); s2[g] += __shfl_xor(s2[g], 32);
+            const float md = s1[g] * invK;
+            const float var = fmaxf(fmaf(-md, md, s2[g] * invK), 0.f);
+            const float rstd = 1.0f / sqrtf(var + a.ln_eps);
+            lnA[g] = rstd;
+            lnB[g] = a.ln_b ? -(sh[g] + md) * rstd : 0.f;
+        }
+    }
+
+    float4 xr[8];
+    u32x4 wr[WPT];
+    // channel 32c + 8kq + i of block c: sources are cut at multiples of 32 channels (launch_conv1x1 checks), channels past K
+    // re-read the last one (their weights are zero)
+    auto load_x_block = [&](int c) {
+        const int cb = 32 * c;
+        const bool first = cb < a.C1;
+        const float* src = (first ? a.x1 : a.x2) + (size_t)b * (size_t)(first ? a.x1_bstride : a.x2_bstride);
+        const int cloc = first ? cb : cb - a.C1, cmax = (first ? a.C1 : a.C2) - 1;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            int ch = cloc + 8 * kq + i;
+            ch = ch < cmax ? ch : cmax;
+            xr[i] = ldv(src, (unsigned)ch * (unsigned)P + pl);
+        }
+    };
+    auto load_w_block = [&](int c) {
+#pragma unroll
+        for (int i = 0; i < WPT; ++i) {
+            const int idx = tid + 256 * i;                       // (t, piece, lane) of this workgroup's slice
+            const int t = idx / 192, rem = idx - t * 192;
+            const bool ok = idx < NCO * 192 && t < tcnt;
+            const u32x4 v = wp3[((size_t)c * NT + t0 + (ok ? t : 0)) * 192 + (ok ? rem : 0)];
+            wr[i] = ok ? v : (u32x4){0u, 0u, 0u, 0u};
+        }
+    };
+    auto store_w_block = [&](int buf) {
+#pragma unroll
+        for (int i = 0; i < WPT; ++i)
+            if (tid + 256 * i < NCO * 192) lds_w[buf][tid + 256 * i] = wr[i];
+    };
+
+    load_x_block(0);
+    load_w_block(0);
+    store_w_block(0);
+    __syncthreads();
+    for (int c = 0; c < NB; ++c) {
+        // ---- LayerNorm + three-piece split of this block's 8 channels x 4 pixels
+        u32x4 bp[4][3];
+#pragma unroll
+        for (int hp = 0; hp < 4; ++hp) {          // channel pair (2 hp, 2 hp + 1) -> dword hp of every operand
+            float xa[4] = {xr[2 * hp].x, xr[2 * hp].y, xr[2 * hp].z, xr[2 * hp].w};
+            float xb[4] = {xr[2 * hp + 1].x, xr[2 * hp + 1].y, xr[2 * hp + 1].z, xr[2 * hp + 1].w};
+            if constexpr (LN) {
+                const int k = 32 * c + 8 * kq + 2 * hp;
+                const float ga = gam_l[k], ba = bet_l[k], gb = gam_l[k + 1], bb = bet_l[k + 1];
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    xa[g] = fmaf(fmaf(xa[g], lnA[g], lnB[g]), ga, ba);
+                    xb[g] = fmaf(fmaf(xb[g], lnA[g], lnB[g]), gb, bb);
+                }
+            }
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                unsigned a0, a1, a2, b0, b1, b2;
+                b3_split(xa[g], a0, a1, a2);
+                b3_split(xb[g], b0, b1, b2);
+                bp[g][0][hp] = b3_pack(a0, b0);
+                bp[g][1][hp] = b3_pack(a1, b1);
+                bp[g][2][hp] = b3_pack(a2, b2);
+            }
+        }
+        if (c + 1 < NB) {   // next block in flight while this one is in the matrix pipe (x into the registers just vacated)
+            load_x_block(c + 1);
+            load_w_block(c + 1);
+        }
+        const u32x4* wl = &lds_w[c & 1][lane];
+#pragma unroll
+        for (int t = 0; t < NCO; ++t) {
+            const u32x4 ap[3] = {wl[(t * 3 + 0) * 64], wl[(t * 3 + 1) * 64], wl[(t * 3 + 2) * 64]};
+#pragma unroll
+            for (int g = 0; g < 4; ++g) acc[t][g] = b3_mfma(ap, bp[g], acc[t][g]);
+        }
+        if (c + 1 < NB) store_w_block((c + 1) & 1);
+        __syncthreads();
+    }
+    epilogue<NCO, false>(a, acc, t0, tcnt, bias_l, nullptr, b, p0, kq, live);
+}
+
 // ---------------------------------------------------------------------------------------------
 // Ragged shapes (P % 4 != 0, unaligned views): one thread per output pixel and channel, plain
 // FMA over K with a two-pass LayerNorm.  Correctness path only: tiny odd test frames (a RawFormer level always has
@@ -499,6 +664,15 @@ static void launch_res(const Conv1x1Args& a, int ntw, int ngroups, dim3 grid, si
     }
 }
 
+// shapes the b3 kernel takes: K-blocks of 32 channels must not straddle the two sources; K < 128 stays on the resident-input
+// f32 kernels, which read x once whatever Cout is and are HBM-bound there (measured per shape with tools/kbench.py:
+// b3 wins 1.05-1.4 x from K = 128 up, loses 0.75-0.95 x at K = 64)
+static bool b3_supported(const Conv1x1Args& a) {
+    const int K = a.C1 + a.C2;
+    return K >= 128 && a.C1 % 8 == 0 && a.C2 % 8 == 0 && (a.C2 == 0 || a.C1 % 32 == 0) && (!a.ln_w || K <= kStreamLnMaxK) &&
+           aligned16(a.wp3) && (a.wp3_bstride % 4 == 0);
+}
+
 int launch_conv1x1(const Conv1x1Args& a, hipStream_t st) {
     RF_CHECK_ARG(a.B > 0 && a.P > 0 && a.C1 > 0 && a.C2 >= 0 && a.Cout > 0, "conv1x1: bad sizes B=%d P=%d C1=%d C2=%d Cout=%d",
                  a.B, a.P, a.C1, a.C2, a.Cout);
@@ -515,11 +689,30 @@ int launch_conv1x1(const Conv1x1Args& a, hipStream_t st) {
     const double px = (double)a.B * a.P;
     const double work_flops = 2.0 * K * a.Cout * px, work_bytes = 4.0 * px * (K + a.Cout + (a.res ? a.Cout : 0));
     char key[64];
+    bool use_b3 = a.wp3 && b3_supported(a);
+#ifdef RF_DIAG   // diagnostic build only (build.py --diag): force the f32 MFMA kernels
+    if (getenv("RF_NO_B3")) use_b3 = false;
+#endif
     if (!vec || (a.res && a.Cout % 16 != 0) || (a.ln_w && K > kStreamLnMaxK)) {
         ProfScope prof(st, "conv1x1_scalar_kernel", work_flops, work_bytes);
         int gx = cdiv(a.P, 256);
         if (gx > 4096) gx = 4096;
         conv1x1_scalar_kernel<<<dim3((unsigned)gx, (unsigned)a.B), 256, 0, st>>>(a);
+    } else if (use_b3) {
+        // bf16x3 streaming kernel (K > 32: below that the resident-input f32 kernels are HBM-bound anyway)
+        // 6 tiles per workgroup where that divides the output evenly; never with the LayerNorm prologue (that instantiation
+        // needs 2 registers more than the 256 a wave has at two waves per SIMD)
+        const int nco = (!a.ln_w && (NT % 6 == 0 || (NT % 4 != 0 && NT > 8))) ? 6 : 4;
+        const int ngroups = cdiv(NT, nco);
+        dim3 grid((unsigned)(cdiv(a.P, 256) * ngroups), (unsigned)a.B, 1);
+        snprintf(key, sizeof(key), "conv1x1_b3_kernel<%d, %s>", nco, a.ln_w ? "true" : "false");
+        ProfScope prof(st, key, work_flops, work_bytes);
+        if (nco == 6) {
+            conv1x1_b3_kernel<6, false><<<grid, 256, 0, st>>>(a, ngroups);
+        } else {
+            if (a.ln_w) conv1x1_b3_kernel<4, true><<<grid, 256, 0, st>>>(a, ngroups);
+            else conv1x1_b3_kernel<4, false><<<grid, 256, 0, st>>>(a, ngroups);
+        }
     } else if (NS <= 16 || (NS <= 32 && !a.ln_w && !a.res)) {
         const int ks = NS <= 4 ? 4 : NS <= 8 ? 8 : NS <= 12 ? 12 : NS <= 16 ? 16 : NS <= 24 ? 24 : 32;
         // output tiles per workgroup: weight slice <= ~60 KB, and <= 8 tiles when the residual rows

@@ -22,7 +22,7 @@ struct Param {
     }
 };
 
-enum PackKind { PK_1x1, PK_3x3, PK_CONVT };
+enum PackKind { PK_1x1, PK_3x3, PK_CONVT, PK_1x1_B3 };
 struct PackItem {
     int param;       // index of the raw weight
     PackKind kind;
@@ -36,6 +36,7 @@ struct rf_handle {
     std::unordered_map<std::string, int> index;
     std::vector<PackItem> packs;
     std::unordered_map<std::string, int> pack_index;   // weight name -> packs[]
+    std::unordered_map<std::string, int> pack3_index;  // weight name -> packs[] entry of its b3 form
     size_t packed_floats = 0;
     size_t upcat_offset[3] = {0, 0, 0};   // composed decoder-step weights (rf_upcat.hip), floats into the packed buffer
     const float* packed = nullptr;   // caller memory, valid after rf_pack_params
@@ -64,9 +65,10 @@ void add_pack(rf_handle* h, const std::string& name, PackKind kind) {
     it.offset = h->packed_floats;
     if (kind == PK_1x1) it.floats = packed1x1_floats((int)p.shape[1], (int)p.shape[0]);
     else if (kind == PK_3x3) it.floats = packed3x3_floats((int)p.shape[1], (int)p.shape[0]);
+    else if (kind == PK_1x1_B3) it.floats = packed1x1_b3_floats((int)p.shape[1], (int)p.shape[0]);
     else it.floats = packed1x1_floats((int)p.shape[0], 4 * (int)p.shape[1]);
     h->packed_floats += align_up(it.floats, 64);
-    h->pack_index[name] = (int)h->packs.size();
+    (kind == PK_1x1_B3 ? h->pack3_index : h->pack_index)[name] = (int)h->packs.size();
     h->packs.push_back(it);
 }
 
@@ -117,18 +119,25 @@ void add_stage(rf_handle* h, int i, int C, int heads) {
     add_pack(h, t + "attn.qkv.weight", PK_1x1);
     add_pack(h, t + "ffn.pointwise1.weight", PK_1x1);
     add_pack(h, t + "ffn.pointwise2.weight", PK_1x1);
-    if (cfg.variant != RF_VARIANT_FLCA) add_pack(h, pre + "channel_reduce.weight", PK_1x1);
+    add_pack(h, t + "attn.qkv.weight", PK_1x1_B3);          // b3 forms for the bf16x3 GEMM kernels (rf_common.h)
+    add_pack(h, t + "ffn.pointwise1.weight", PK_1x1_B3);
+    add_pack(h, t + "ffn.pointwise2.weight", PK_1x1_B3);
+    if (cfg.variant != RF_VARIANT_FLCA) {
+        add_pack(h, pre + "channel_reduce.weight", PK_1x1);
+        add_pack(h, pre + "channel_reduce.weight", PK_1x1_B3);
+    }
     add_pack(h, pre + "Conv_out.weight", PK_3x3);
 }
 
 const float* P(const rf_handle* h, const std::string& name) { return h->params[h->index.at(name)].ptr; }
 const float* PK(const rf_handle* h, const std::string& name) { return h->packed + h->packs[h->pack_index.at(name)].offset; }
+const float* PK3(const rf_handle* h, const std::string& name) { return h->packed + h->packs[h->pack3_index.at(name)].offset; }
 
 // ---- workspace plan ---------------------------------------------------------------------
 struct Plan {
     size_t total = 0;
     size_t gscratch, guide[4], skip[3], tA, tB, tU, bufA, bufB, x1, trans, xs, cr;
-    size_t gram_partial, wfold_attn, wfold_cr, flca_partial, ch;
+    size_t gram_partial, wfold_attn, wfold_cr, wfold_attn3, wfold_cr3, flca_partial, ch;
 };
 
 size_t take(Plan& p, size_t floats) {
@@ -154,7 +163,7 @@ int make_plan(const rf_handle* h, int B, int H, int W, Plan& p) {
     p.trans = take(p, U0);
     p.xs = take(p, U0);
     p.cr = take(p, U0);
-    size_t gp = 0, wa = 0, wc = 0, fp = 0;
+    size_t gp = 0, wa = 0, wc = 0, fp = 0, wa3 = 0, wc3 = 0;
     for (int l = 0; l < 4; ++l) {
         const int C = c.dim << l, Pl = (H >> l) * (W >> l);
         int ns, sl;
@@ -175,12 +184,17 @@ int make_plan(const rf_handle* h, int B, int H, int W, Plan& p) {
         const size_t a = (size_t)B * packed1x1_floats(C, C), cr = (size_t)B * packed1x1_floats(2 * C, C);
         if (a > wa) wa = a;
         if (cr > wc) wc = cr;
+        const size_t a3 = (size_t)B * packed1x1_b3_floats(C, C), cr3 = (size_t)B * packed1x1_b3_floats(2 * C, C);
+        if (a3 > wa3) wa3 = a3;
+        if (cr3 > wc3) wc3 = cr3;
         const size_t f = (size_t)B * flca_nblk(H >> l, W >> l) * C;
         if (f > fp) fp = f;
     }
     p.gram_partial = take(p, gp);
     p.wfold_attn = take(p, wa);
     p.wfold_cr = take(p, wc);
+    p.wfold_attn3 = take(p, wa3);
+    p.wfold_cr3 = take(p, wc3);
     p.flca_partial = take(p, fp);
     p.ch = take(p, (size_t)B * (c.dim << 3));
     return RF_OK;
@@ -213,7 +227,8 @@ int run_stage(const rf_handle* h, int i, int lvl, const float* in, float* out, f
     tp.pw1_wp = PK(h, t + "ffn.pointwise1.weight"); tp.pw1_b = P(h, t + "ffn.pointwise1.bias");
     tp.dw_w = P(h, t + "ffn.depthwise.weight"); tp.dw_b = P(h, t + "ffn.depthwise.bias");
     tp.pw2_wp = PK(h, t + "ffn.pointwise2.weight"); tp.pw2_b = P(h, t + "ffn.pointwise2.bias");
-    TbBufOffsets to{p.bufA, p.bufB, p.x1, p.gram_partial, p.wfold_attn};
+    tp.qkv_wp3 = PK3(h, t + "attn.qkv.weight"); tp.pw1_wp3 = PK3(h, t + "ffn.pointwise1.weight"); tp.pw2_wp3 = PK3(h, t + "ffn.pointwise2.weight");
+    TbBufOffsets to{p.bufA, p.bufB, p.x1, p.gram_partial, p.wfold_attn, p.wfold_attn3};
     RF_TRY(run_transformer(tp, in, trans, ws, to, B, C, heads, hc, hh, ww, st));
 
     // branch, cat, channel_reduce -------------------------------------------------------------
@@ -233,8 +248,9 @@ int run_stage(const rf_handle* h, int i, int lvl, const float* in, float* out, f
         const int hid = C / 8 > 8 ? C / 8 : 8;
         RF_TRY(launch_flca_se_fold(s.partial, s.nblk, Pn, P(h, f + "se.1.weight"), P(h, f + "se.1.bias"),
                                    P(h, f + "se.3.weight"), P(h, f + "se.3.bias"), hid, P(h, pre + "channel_reduce.weight"),
-                                   ws + p.wfold_cr, ws + p.ch, B, C, st));
+                                   ws + p.wfold_cr, ws + p.wfold_cr3, ws + p.ch, B, C, st));
         r.wp = ws + p.wfold_cr; r.wp_bstride = (int64_t)packed1x1_floats(2 * C, C);
+        r.wp3 = ws + p.wfold_cr3; r.wp3_bstride = (int64_t)packed1x1_b3_floats(2 * C, C);
     } else {
         Conv3x3Args cb{};
         cb.x = in; cb.x_bstride = (int64_t)C * Pn; cb.wp = PK(h, pre + "conv.weight"); cb.bias = P(h, pre + "conv.bias");
@@ -242,6 +258,7 @@ int run_stage(const rf_handle* h, int i, int lvl, const float* in, float* out, f
         cb.act = cfg.branch_lrelu ? 1 : 0;
         RF_TRY(launch_conv3x3(cb, st));
         r.wp = PK(h, pre + "channel_reduce.weight");
+        r.wp3 = PK3(h, pre + "channel_reduce.weight");
     }
     RF_TRY(launch_conv1x1(r, st));
 
@@ -364,6 +381,7 @@ int rf_pack_params(rf_handle* h, void* packed_dev, size_t bytes, void* stream) {
         const Param& p = h->params[it.param];
         int rc;
         if (it.kind == PK_1x1) rc = pack_1x1(p.ptr, base + it.offset, (int)p.shape[0], (int)p.shape[1], p.shape[1], 1, st);
+        else if (it.kind == PK_1x1_B3) rc = pack_1x1_b3(p.ptr, base + it.offset, (int)p.shape[0], (int)p.shape[1], p.shape[1], 1, st);
         else if (it.kind == PK_3x3) rc = pack_3x3(p.ptr, base + it.offset, (int)p.shape[0], (int)p.shape[1], st);
         else rc = pack_convT(p.ptr, base + it.offset, (int)p.shape[0], (int)p.shape[1], st);
         if (rc) return rc;

@@ -25,6 +25,25 @@ int pack_1x1(const float* w, float* packed, int Cout, int K, int64_t row_stride,
     return check_launch("pack_1x1");
 }
 
+// b3 form of the same matrix (rf_common.h): three bf16 pieces per weight, zero outside [Cout] x [K]
+__global__ void __launch_bounds__(256) pack_1x1_b3_kernel(const float* __restrict__ w, unsigned short* __restrict__ packed3,
+                                                          int Cout, int K, int64_t row_stride, int64_t col_stride) {
+    const int NT = (Cout + 15) >> 4, NB = (K + 31) >> 5;
+    const size_t total = (size_t)NT * NB * 512;          // (co, k) pairs of the padded matrix
+    for (size_t idx = blockIdx.x * 256ull + threadIdx.x; idx < total; idx += (size_t)gridDim.x * 256) {
+        const int k = (int)(idx % ((size_t)NB * 32)), co = (int)(idx / ((size_t)NB * 32));
+        b3_store(packed3, NT, co, k, (co < Cout && k < K) ? w[co * row_stride + k * col_stride] : 0.f);
+    }
+}
+
+int pack_1x1_b3(const float* w, void* packed3, int Cout, int K, int64_t row_stride, int64_t col_stride, hipStream_t st) {
+    const size_t total = (size_t)cdiv(Cout, 16) * cdiv(K, 32) * 512;
+    int g = (int)((total + 255) / 256);
+    if (g > 4096) g = 4096;
+    pack_1x1_b3_kernel<<<g, 256, 0, st>>>(w, (unsigned short*)packed3, Cout, K, row_stride, col_stride);
+    return check_launch("pack_1x1_b3");
+}
+
 // nn.ConvTranspose2d weight [Cin][Cout][2][2]: GEMM row 4*o + 2*i + j, column k
 int pack_convT(const float* w, float* packed, int Cin, int Cout, hipStream_t st) {
     return pack_1x1(w, packed, 4 * Cout, Cin, 1, (int64_t)4 * Cout, st);

@@ -295,6 +295,18 @@ def test_transformer_block_oracle_mid_levels(ops, device, c, heads, hw):
     close(ops.transformer_block(x.to(device), dev(p, device), heads=heads), ref)
 
 
+@pytest.mark.parametrize("shape", [(2, 32, 256, 512), (8, 32, 128, 256)])
+def test_transformer_block_persistent_workgroups(ops, device, shape):
+    """Level-0 fused kernels with SEVERAL tiles per persistent workgroup and both co-resident workgroups of every CU busy
+    (512 workgroups): the small cases above give each workgroup at most one tile of the fused FFN."""
+    c, heads = 32, 8
+    p = params(cases.transformer_spec(c))
+    x = rnd("tb.big.x", shape)
+    torch.set_num_threads(max(torch.get_num_threads(), 8))
+    ref = R.transformer_block(x, p, "", heads)
+    close(ops.transformer_block(x.to(device), dev(p, device), heads=heads), ref)
+
+
 def test_transformer_block_ffn_expansion_4(ops, device):
     """expansion 4 takes the op-by-op FFN whose hidden tensor is 4C wide (scratch sized for it)."""
     c, heads, hw = 32, 8, (16, 24)
