@@ -74,6 +74,14 @@ SIGNATURES = {
     "rf_luma_film": (_i, [_vp, _vp, _vp, C.c_longlong, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
     "rf_dwgate3x3": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
     "rf_dwconv5x5": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
+    "rf_rfft2_polar_scratch_bytes": (_i, [_i, _i, _i, _psz]),
+    "rf_rfft2_polar": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _vp]),
+    "rf_polar_irfft2": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _vp]),
+    "rf_feb_scratch_bytes": (_i, [_i, _i, _i, _i, _psz]),
+    "rf_feb": (_i, [_vp, _vp, C.POINTER(_vp), _vp, _i, _i, _i, _i, _vp]),
+    "rf_ffab_scratch_bytes": (_i, [_i, _i, _i, _i, _psz]),
+    "rf_ffab": (_i, [_vp, _vp, C.POINTER(_vp), _vp, _i, _i, _i, _i, _vp]),
+    "rf_affine_clamp_add": (_i, [_vp, _vp, _vp, _sz, _f, _f, _f, _f, _vp]),
     "rf_upcat_scratch_bytes": (_i, [_i, _psz]),
     "rf_upcat": (_i, [_vp] * 8 + [_i, _i, _i, _i, _vp]),
 }

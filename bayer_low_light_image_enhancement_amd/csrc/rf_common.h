@@ -158,7 +158,7 @@ struct Conv1x1Args {
     int B, P;              // images, pixels per image
     int w;                 // image width (mode 1 only)
     int mode;              // 0: out[co][p]; 1: ConvTranspose2d 2x2 scatter, row co = 4*o + 2*i + j
-    int act;               // 0 none, 1 LeakyReLU(0.2), 2 ReLU
+    int act;               // 0 none, 1 LeakyReLU(0.2), 2 ReLU, 3 LeakyReLU(0.1), 4 clamp to [0, 1e4] (FEB, blocks.py:14-30)
 };
 int launch_conv1x1(const Conv1x1Args& a, hipStream_t st);
 
@@ -241,6 +241,12 @@ struct TbBufOffsets { size_t bufA, bufB, x1, partial, wfold, wfold3; };   // flo
 size_t transformer_scratch_floats(int B, int C, int heads, int hc, int h, int w, TbBufOffsets* o);
 int run_transformer(const TbParams& p, const float* in, float* out, float* ws, const TbBufOffsets& o,
                     int B, int C, int heads, int hc, int hh, int ww, hipStream_t st);
+
+// ---- rfft2 / irfft2 with the polar maps of FEB (rf_fft.hip); cscratch: planes * h * (w/2 + 1) complex values
+int launch_rfft2_polar(const float* in, float* mag, float* pha, float2* cscratch, int planes, int h, int w, hipStream_t st);
+int launch_polar_irfft2(const float* mag, const float* pha, const float* res, float* out, float2* cscratch, int planes, int h, int w,
+                        float lim, hipStream_t st);
+int launch_clamp(const float* in, float* out, size_t n, float lo, float hi, hipStream_t st);
 
 // ---- FLCA (rf_flca.hip)
 size_t guidance_scratch_floats(int B, int H, int W);

@@ -71,12 +71,16 @@ __device__ __forceinline__ void epilogue(const Conv1x1Args& a, f32x4 (&acc)[NCO]
                     const float4 rv = res[t * 4 + r];
                     v[0] += rv.x; v[1] += rv.y; v[2] += rv.z; v[3] += rv.w;
                 }
-                if (a.act == 1) {
+                if (a.act == 1 || a.act == 3) {
+                    const float slope = a.act == 1 ? 0.2f : 0.1f;
 #pragma unroll
-                    for (int g = 0; g < 4; ++g) v[g] = v[g] > 0.f ? v[g] : 0.2f * v[g];
+                    for (int g = 0; g < 4; ++g) v[g] = v[g] > 0.f ? v[g] : slope * v[g];
                 } else if (a.act == 2) {
 #pragma unroll
                     for (int g = 0; g < 4; ++g) v[g] = fmaxf(v[g], 0.f);
+                } else if (a.act == 4) {
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) v[g] = fminf(fmaxf(v[g], 0.f), 1e4f);
                 }
                 if (live && cu + 4 * kq < a.Cout)
                     *reinterpret_cast<float4*>(outb + (size_t)cu * P + voff) = make_float4(v[0], v[1], v[2], v[3]);
@@ -635,6 +639,8 @@ __global__ void __launch_bounds__(256) conv1x1_scalar_kernel(Conv1x1Args a) {
                 if (a.res) s += a.res[(size_t)b * a.res_bstride + (size_t)co * P + p];
                 if (a.act == 1) s = s > 0.f ? s : 0.2f * s;
                 else if (a.act == 2) s = fmaxf(s, 0.f);
+                else if (a.act == 3) s = s > 0.f ? s : 0.1f * s;
+                else if (a.act == 4) s = fminf(fmaxf(s, 0.f), 1e4f);
                 a.out[(size_t)b * a.out_bstride + (size_t)co * P + p] = s;
             } else {
                 const int o = co >> 2, y = p / a.w, x = p - y * a.w;

@@ -523,3 +523,98 @@ def bayer_luma(mosaic: torch.Tensor, pattern: str = "rggb") -> torch.Tensor:
     with torch.cuda.device(mosaic.device):
         _lib.check(lib.rf_bayer_luma(_ptr(mosaic), _ptr(out), _ptr(scratch), b, h, w, pat, _stream(mosaic)), "rf_bayer_luma")
     return out
+
+
+# ------------------------------------------------------------------------------------------ FFAB / FEB (f2)
+_FEB_KEYS = ("fpre.weight", "fpre.bias", "process1.0.weight", "process1.0.bias", "process1.2.weight", "process1.2.bias",
+             "process2.0.weight", "process2.0.bias", "process2.2.weight", "process2.2.bias")
+_PB_KEYS = tuple("frequency_process." + k for k in _FEB_KEYS) + ("cat.weight", "cat.bias")
+_FFAB_KEYS = (("conv0.0.weight", "conv0.0.bias") + tuple("conv0.1." + k for k in _PB_KEYS)
+              + tuple(f"conv{i}." + k for i in (1, 2, 3) for k in _PB_KEYS)
+              + tuple(f"{n}.0." + k for n in ("conv4",) for k in _PB_KEYS) + ("conv4.1.weight", "conv4.1.bias")
+              + tuple("conv5.0." + k for k in _PB_KEYS) + ("conv5.1.weight", "conv5.1.bias")
+              + tuple("convout.0." + k for k in _PB_KEYS) + ("convout.1.weight", "convout.1.bias"))
+
+
+def rfft2_polar(x: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
+    """``f = torch.fft.rfft2(x, norm='ortho'); (f.abs() + 1e-6, f.angle())`` (FEB, RawFomer_WFB_FFAB/blocks.py:27-29)."""
+    x = _chk(x, "x")
+    b, c, h, w = x.shape
+    lib = _lib.load()
+    sz = C.c_size_t()
+    _lib.check(lib.rf_rfft2_polar_scratch_bytes(b * c, h, w, C.byref(sz)), "rf_rfft2_polar_scratch_bytes")
+    scratch = _scratch(sz.value, x)
+    mag = torch.empty((b, c, h, w // 2 + 1), dtype=x.dtype, device=x.device)
+    pha = torch.empty_like(mag)
+    with torch.cuda.device(x.device):
+        _lib.check(lib.rf_rfft2_polar(_ptr(x), _ptr(mag), _ptr(pha), _ptr(scratch), b * c, h, w, _stream(x)), "rf_rfft2_polar")
+    return mag, pha
+
+
+def polar_irfft2(mag: torch.Tensor, pha: torch.Tensor, width: int) -> torch.Tensor:
+    """``torch.fft.irfft2(torch.complex(mag * cos(pha), mag * sin(pha)), s=(h, width), norm='ortho')`` (blocks.py:32-35)."""
+    mag, pha = _chk(mag, "mag"), _chk(pha, "pha")
+    b, c, h, wf = mag.shape
+    if wf != width // 2 + 1:
+        raise RuntimeError(f"half spectrum of width {wf} does not belong to an output width of {width}")
+    lib = _lib.load()
+    sz = C.c_size_t()
+    _lib.check(lib.rf_rfft2_polar_scratch_bytes(b * c, h, width, C.byref(sz)), "rf_rfft2_polar_scratch_bytes")
+    scratch = _scratch(sz.value, mag)
+    out = torch.empty((b, c, h, width), dtype=mag.dtype, device=mag.device)
+    with torch.cuda.device(mag.device):
+        _lib.check(lib.rf_polar_irfft2(_ptr(mag), _ptr(pha), _ptr(out), _ptr(scratch), b * c, h, width, _stream(mag)), "rf_polar_irfft2")
+    return out
+
+
+def _ptr_array(ts):
+    return (C.c_void_p * len(ts))(*[t.data_ptr() for t in ts])
+
+
+def feb(x: torch.Tensor, params, prefix: str = "") -> torch.Tensor:
+    """``FEB(nc)(x)`` (RawFomer_WFB_FFAB/blocks.py:11-39)."""
+    x = _chk(x, "x")
+    b, c, h, w = x.shape
+    ts = [_chk(params[prefix + k], k) for k in _FEB_KEYS]
+    lib = _lib.load()
+    sz = C.c_size_t()
+    _lib.check(lib.rf_feb_scratch_bytes(b, c, h, w, C.byref(sz)), "rf_feb_scratch_bytes")
+    scratch = _scratch(sz.value, x)
+    out = torch.empty_like(x)
+    with torch.cuda.device(x.device):
+        _lib.check(lib.rf_feb(_ptr(x), _ptr(out), _ptr_array(ts), _ptr(scratch), b, c, h, w, _stream(x)), "rf_feb")
+    return out
+
+
+def ffab(x: torch.Tensor, params, prefix: str = "") -> torch.Tensor:
+    """``FFAB(nc)(x)`` (RawFomer_WFB_FFAB/blocks.py:59-92): seven ProcessBlocks (FEB + 1x1 + residual), dense concatenations."""
+    x = _chk(x, "x")
+    b, c, h, w = x.shape
+    ts = [_chk(params[prefix + k], k) for k in _FFAB_KEYS]
+    lib = _lib.load()
+    sz = C.c_size_t()
+    _lib.check(lib.rf_ffab_scratch_bytes(b, c, h, w, C.byref(sz)), "rf_ffab_scratch_bytes")
+    scratch = _scratch(sz.value, x)
+    out = torch.empty_like(x)
+    with torch.cuda.device(x.device):
+        _lib.check(lib.rf_ffab(_ptr(x), _ptr(out), _ptr_array(ts), _ptr(scratch), b, c, h, w, _stream(x)), "rf_ffab")
+    return out
+
+
+def wmb_ll_branch(x: torch.Tensor, params, prefix: str = "", high=None) -> torch.Tensor:
+    """The wavelet branch of ``WMB.forward`` (RawFomer_WFB_FFAB/model.py:215-243) with the Mamba module ``mb`` (``mamba_ssm``:
+    absent offline, parity unpinned) replaced by ``high`` (a callable on the ``[3B,C,h/2,w/2]`` high bands; identity when
+    ``None``):  ``t = 2 LN(x) - 1;  LL, hi = DWT(t);  LL = FFAB(illu(LL)[0]);  t + clamp((IWT(cat(LL, high(hi))) + 1) / 2, 0, 1)``.
+    ``2 LN(x) - 1`` is the LayerNorm kernel with weight ``2 w`` and bias ``2 b - 1``."""
+    x = _chk(x, "x")
+    n = x.shape[0]
+    t = layernorm2d(x, 2.0 * params[prefix + "norm1.body.weight"], 2.0 * params[prefix + "norm1.body.bias"] - 1.0)
+    d = dwt_init(t)
+    fea, _ = illumination_estimator(d[:n].contiguous(), params, prefix + "illu.")
+    ll = ffab(fea, params, prefix + "ffab.")
+    hi = d[n:] if high is None else high(d[n:])
+    y = iwt_init(torch.cat((ll, hi), dim=0))
+    out = torch.empty_like(t)
+    with torch.cuda.device(x.device):
+        _lib.check(_lib.load().rf_affine_clamp_add(_ptr(y), _ptr(t), _ptr(out), t.numel(), 0.5, 0.5, 0.0, 1.0, _stream(x)), "rf_affine_clamp_add")
+    return out

@@ -164,6 +164,25 @@ int rf_flca(const float* feat, const float* guide, float* out, const float* cons
 int rf_guidance_scratch_bytes(int B, int H, int W, size_t* bytes);
 int rf_flca_guidance(const float* packed, float* guide, void* scratch, int B, int H, int W, int hf, int wf, void* stream);
 
+/* ---- FFAB / FEB: the frequency block of the WFB variant (RawFomer_WFB_FFAB/blocks.py:11-92) ------------------------
+ * rfft2 / irfft2 are hand-written LDS transforms (power-of-two lines: radix 2; any other length up to 2048: direct DFT);
+ * norm='ortho'.  Widths must be even (irfft2 with s=(H,W) inverts rfft2 only then).
+ * rf_rfft2_polar: [planes,h,w] -> |F| + 1e-6 and angle(F), each [planes,h,w/2+1]  (FEB, blocks.py:27-29)
+ * rf_polar_irfft2: mag, pha [planes,h,w/2+1] -> irfft2(mag e^{i pha}) [planes,h,w]  (blocks.py:32-35) */
+int rf_rfft2_polar_scratch_bytes(int planes, int h, int w, size_t* bytes);
+int rf_rfft2_polar(const float* in, float* mag, float* pha, void* scratch, int planes, int h, int w, void* stream);
+int rf_polar_irfft2(const float* mag, const float* pha, float* out, void* scratch, int planes, int h, int w, void* stream);
+/* FEB.forward (blocks.py:23-39).  prm = HOST array of 10 device pointers in state_dict order:
+ * fpre.{w,b}, process1.0.{w,b}, process1.2.{w,b}, process2.0.{w,b}, process2.2.{w,b}.  [B,nc,h,w] -> same. */
+int rf_feb_scratch_bytes(int B, int nc, int h, int w, size_t* bytes);
+int rf_feb(const float* in, float* out, const float* const* prm, void* scratch, int B, int nc, int h, int w, void* stream);
+/* FFAB.forward (blocks.py:83-92).  prm = HOST array of the module's 92 tensors in state_dict order
+ * (conv0.0.{w,b}, conv0.1.<ProcessBlock: 10 FEB tensors, cat.{w,b}>, conv1..conv3, conv4.0.<PB>, conv4.1.{w,b}, conv5.*, convout.*). */
+int rf_ffab_scratch_bytes(int B, int nc, int h, int w, size_t* bytes);
+int rf_ffab(const float* in, float* out, const float* const* prm, void* scratch, int B, int nc, int h, int w, void* stream);
+/* out = add + clamp(in * scale + shift, lo, hi): inverse_data_transform + residual of WMB (model.py:13-15, 241-243). */
+int rf_affine_clamp_add(const float* in, const float* add, float* out, size_t n, float scale, float shift, float lo, float hi, void* stream);
+
 /* Decoder step of RawFormer.forward (RawFomer_WFB_FFAB/model.py:461-468, 494-503) as one kernel on composed weights:
  *   out = Conv2d(2C, C, 1)(cat[ConvTranspose2d(2C, C, 2, stride=2)(x), skip])
  * x [B,2C,h,w], skip and out [B,C,2h,2w]; up_w [2C,C,2,2], up_b [C], cr_w [C,2C,1,1], cr_b [C]; w % 4 == 0. */

@@ -429,6 +429,71 @@ def wfb_extras():
     save("wfb_extras", **out)
 
 
+FFT_CASES = (("p2", (2, 3, 16, 32)), ("mixed", (1, 2, 10, 14)), ("sq", (1, 2, 64, 64)), ("tall", (1, 1, 24, 8)))
+FEB_CASES = (("feb16", 16, (2, 16, 16, 16)), ("feb8", 8, (1, 8, 12, 20)))
+FFAB_CASES = (("ffab16", 16, (2, 16, 16, 16)), ("ffab8", 8, (1, 8, 8, 12)))
+WMB_CASES = (("wmb16", 16, (2, 16, 16, 24)),)
+
+
+def ffab(blocks_mod, wfb_ns):
+    """f2: ``FEB`` / ``FFAB`` of RawFomer_WFB_FFAB/blocks.py:11-92 (the module imports with inert timm stubs), the two
+    transforms it is built on, and the Mamba-free wavelet branch of ``WMB.forward`` (model.py:215-243) assembled from the
+    reference's own modules in the reference's order with ``mb`` left out (``mamba_ssm`` is absent: parity unpinned)."""
+    out = {}
+    for tag, shape in FFT_CASES:
+        x = rnd(71, f"fft.{tag}.x", shape)
+        f = torch.fft.rfft2(x, norm="ortho")
+        out[f"fft.{tag}.mag"], out[f"fft.{tag}.pha"] = f.abs() + 1e-6, torch.angle(f)
+        mag = rnd(72, f"fft.{tag}.mag", f.shape, 0.0, 2.0)
+        pha = rnd(73, f"fft.{tag}.pha", f.shape, -3.0, 3.0)
+        out[f"fft.{tag}.inv"] = torch.fft.irfft2(torch.complex(mag * torch.cos(pha), mag * torch.sin(pha)), s=shape[-2:], norm="ortho")
+    for tag, nc, shape in FEB_CASES:
+        m = fill(blocks_mod.FEB(nc), 1000 + nc)
+        x = rnd(61, f"ffab.{tag}.x", shape, -1.5, 1.5)
+        with torch.no_grad():
+            y = m(x)
+            mine = R.feb(x, sd_of(m), "")
+        log(f"  FEB {tag} nc={nc} {shape}: oracle vs reference {maxabs(y, mine):.2e}, |y|max {float(y.abs().max()):.2f}")
+        assert maxabs(y, mine) < 1e-6
+        out[f"{tag}.out"] = y
+    for tag, nc, shape in FFAB_CASES:
+        m = fill(blocks_mod.FFAB(nc), 2000 + nc)
+        x = rnd(61, f"ffab.{tag}.x", shape)
+        with torch.no_grad():
+            y = m(x)
+            mine = R.ffab(x, sd_of(m), "")
+        log(f"  FFAB {tag} nc={nc} {shape}: oracle vs reference {maxabs(y, mine):.2e}, |y|max {float(y.abs().max()):.2f}")
+        assert maxabs(y, mine) < 1e-6
+        out[f"{tag}.out"] = y
+    # WMB without Mamba: the reference's LayerNorm (WithBias), DWT, Illumination_Estimator, FFAB, IWT in WMB.forward's order
+    src = open(os.path.join(REF, "RawFomer_WFB_FFAB", "model.py")).read()
+    seg = src[src.index("class Illumination_Estimator"):src.index("class WMB(nn.Module)")]
+    ns = {"torch": torch, "nn": torch.nn, "F": torch.nn.functional}
+    exec(compile(seg, "WFB/model.py#illu", "exec"), ns)
+    for tag, nc, shape in WMB_CASES:
+        norm1 = fill(wfb_ns["WithBias_LayerNorm"](nc), 3000 + nc)
+        illu = fill(ns["Illumination_Estimator"](nc, n_fea_in=nc + 1, n_fea_out=nc), 3100 + nc)
+        fb = fill(blocks_mod.FFAB(nc), 3200 + nc)
+        x = rnd(62, f"wmb.{tag}.x", shape)
+        n, c, h, w = shape
+        with torch.no_grad():
+            t = norm1(x.permute(0, 2, 3, 1).reshape(n, h * w, c)).reshape(n, h, w, c).permute(0, 3, 1, 2)    # LayerNorm.forward (to_3d / to_4d)
+            t = 2 * t - 1.0                                                                                # data_transform
+            d = blocks_mod.DWT()(t)
+            ll, hi = d[:n], d[n:]
+            ll, _ = illu(ll)
+            ll = fb(ll)
+            y = t + torch.clamp((blocks_mod.IWT()(torch.cat((ll, hi), dim=0)) + 1.0) / 2.0, 0.0, 1.0)     # inverse_data_transform + residual
+            p = {"norm1.body." + k: v for k, v in sd_of(norm1).items()}
+            p.update({"illu." + k: v for k, v in sd_of(illu).items()})
+            p.update({"ffab." + k: v for k, v in sd_of(fb).items()})
+            mine = R.wmb_ll_branch(x, p, "")
+        log(f"  WMB wavelet branch without mb {tag} nc={nc} {shape}: oracle vs reference modules {maxabs(y, mine):.2e}")
+        assert maxabs(y, mine) < 2e-5          # LayerNorm in a different operation order, amplified by the FFAB chain
+        out[f"{tag}.out"] = y
+    save("ffab", **out)
+
+
 def state_dict_keys(flca_mod):
     """Key names and shapes of the reference's state_dict (what test.py:88-91 loads strictly)."""
     import json
@@ -449,6 +514,7 @@ def main():
     ap.add_argument("--only-harness", action="store_true", help="only the evaluation-harness fixture (test.py helpers)")
     ap.add_argument("--only-attenblock", action="store_true", help="only the Attenblock.LuminanceAwareMHSA (a16) and WFB extras (a17) fixtures")
     ap.add_argument("--only-cfg4", action="store_true", help="only BASELINE config 4 (RawFormer-L, one 2848x4256 mosaic)")
+    ap.add_argument("--only-ffab", action="store_true", help="only the FEB / FFAB / rfft2 / WMB-wavelet-branch fixtures (f2)")
     args = ap.parse_args()
     if args.only_keys:
         os.makedirs(GOLD, exist_ok=True)
@@ -466,6 +532,13 @@ def main():
         with open(os.path.join(GOLD, "PINNING.txt"), "a") as f:
             f.write("\n".join(LOG) + "\n")
         return
+    if args.only_ffab:
+        os.makedirs(GOLD, exist_ok=True)
+        mods = import_reference()
+        ffab(mods[2], mods[4])
+        with open(os.path.join(GOLD, "PINNING.txt"), "a") as f:
+            f.write("\n".join(LOG) + "\n")
+        return
     if args.only_cfg4:
         torch.set_num_threads(8)
         config4(import_reference()[0])
@@ -478,6 +551,7 @@ def main():
     whole_model(mods[0], args.big)
     attenblock()
     wfb_extras()
+    ffab(mods[2], mods[4])
     state_dict_keys(mods[0])
     with open(os.path.join(GOLD, "PINNING.txt"), "w") as f:
         f.write("# written by oracle/make_golden.py: reference (run on CPU here) vs oracle/rawformer_ref.py\n")

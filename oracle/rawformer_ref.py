@@ -478,12 +478,23 @@ def bayer_luma(mosaic: Tensor, pattern: str = "rggb") -> Tensor:
 # ------------------------------------------------------------------------------------------
 # f2: FFAB / FEB (RawFomer_WFB_FFAB/blocks.py:11-92) and the Mamba-free part of WMB (model.py:203-245)
 # ------------------------------------------------------------------------------------------
-def feb(x: Tensor, p: Dict[str, Tensor], pre: str) -> Tensor:
+def feb(x: Tensor, p: Dict[str, Tensor], pre: str, exact_symmetric_bins: bool = False) -> Tensor:
     """FEB.forward (blocks.py:23-39): clamp, 1x1, rfft2 (ortho), |.|+1e-6 and angle through two 1x1 MLPs
-    (LeakyReLU 0.1), clamp of the magnitude to [0, 1e4], polar -> cartesian, irfft2 (ortho), + clamped input, clamp."""
+    (LeakyReLU 0.1), clamp of the magnitude to [0, 1e4], polar -> cartesian, irfft2 (ortho), + clamped input, clamp.
+
+    ``exact_symmetric_bins``: the four bins (0 | h/2, 0 | w/2) of a real 2-D transform are real by symmetry.  The reference's
+    FFT (pocketfft) returns an exact +0 imaginary part there for power-of-two sizes, but rounding noise of either sign
+    (~1e-8) for other sizes, so that ``angle`` of a negative real bin is +pi or -pi at random -- and the phase feeds a 1x1 MLP,
+    which is not 2 pi periodic.  With the flag the imaginary parts are set to +0 (what exact arithmetic gives, and what the
+    HIP transform does); for power-of-two sizes it changes nothing."""
     h, w = x.shape[-2:]
     x = x.clamp(-10.0, 10.0)
     f = torch.fft.rfft2(F.conv2d(x, p[pre + "fpre.weight"], p[pre + "fpre.bias"]), norm="ortho")
+    if exact_symmetric_bins:
+        f = f.clone()
+        for yy in {0, h // 2} if h % 2 == 0 else {0}:
+            for xx in {0, w // 2}:
+                f[..., yy, xx] = torch.complex(f[..., yy, xx].real, torch.zeros_like(f[..., yy, xx].real))
     mag, pha = f.abs() + 1e-6, torch.angle(f)
 
     def mlp(t, name):
