@@ -13,12 +13,13 @@ LIB_PATH = os.environ.get("RF_LIB_PATH") or os.path.join(_HERE, "csrc", "librawf
 
 RF_VARIANT_FLCA = 0
 RF_VARIANT_PLAIN = 1
+RF_VARIANT_TRUECOLOR = 2
 
 
 class RfConfig(C.Structure):
     _fields_ = [("dim", C.c_int32), ("heads", C.c_int32 * 4), ("inp_channels", C.c_int32),
                 ("out_channels", C.c_int32), ("ffn_expansion", C.c_int32), ("variant", C.c_int32),
-                ("branch_lrelu", C.c_int32), ("clamp_io", C.c_int32)]
+                ("branch_lrelu", C.c_int32), ("clamp_io", C.c_int32), ("flca_levels", C.c_int32)]
 
 
 _vp, _i, _f, _sz = C.c_void_p, C.c_int, C.c_float, C.c_size_t

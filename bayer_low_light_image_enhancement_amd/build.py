@@ -21,7 +21,7 @@ LIB = os.path.join(CSRC, "librawformer_hip.so")
 DIAG_LIB = os.path.join(CSRC, "librawformer_hip_diag.so")
 DIAG_SOURCES = ["rf_block.hip", "rf_model.hip", "rf_gemm1x1.hip"]
 SOURCES = ["rf_api.hip", "rf_model.hip", "rf_pack.hip", "rf_pointwise.hip", "rf_gemm1x1.hip",
-           "rf_conv3x3.hip", "rf_attn.hip", "rf_flca.hip", "rf_fused.hip", "rf_block.hip", "rf_harness.hip", "rf_tokattn.hip", "rf_wfb.hip", "rf_upcat.hip", "rf_fft.hip", "rf_ffab.hip"]
+           "rf_conv3x3.hip", "rf_attn.hip", "rf_flca.hip", "rf_fused.hip", "rf_block.hip", "rf_harness.hip", "rf_tokattn.hip", "rf_wfb.hip", "rf_upcat.hip", "rf_fft.hip", "rf_ffab.hip", "rf_truecolor.hip"]
 FLAGS = ["-O3", "-std=c++17", "-fPIC", "--offload-arch=gfx950", "-Wall", "-Wno-unused-function"]
 
 

@@ -351,7 +351,7 @@ int rf_transformer_block(const float* in, float* out, const float* const* prm, v
     RF_TRY(pack_1x1_b3(prm[15], ws + s.w23, C, hc, hc, 1, st));
     TbParams p{prm[0], prm[1], prm[2], ws + s.wqkv, prm[4], prm[5], prm[6], prm[7], prm[8],
                prm[9], prm[10], ws + s.w1, prm[12], prm[13], prm[14], ws + s.w2, prm[16],
-               ws + s.wqkv3, ws + s.w13, ws + s.w23};
+               ws + s.wqkv3, ws + s.w13, ws + s.w23, 0};
     return run_transformer(p, in, out, ws + s.bufs, s.o, B, C, heads, hc, h, w, st);
 }
 

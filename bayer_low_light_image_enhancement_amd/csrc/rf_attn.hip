@@ -178,7 +178,7 @@ int launch_gram(const GramArgs& a, hipStream_t st) {
 __global__ void __launch_bounds__(256) attn_fold_kernel(const float* __restrict__ partial, int nslab,
                                                         const float* __restrict__ temperature,
                                                         const float* __restrict__ w_out, float* __restrict__ wp_out,
-                                                        unsigned short* __restrict__ wp3_out, int C, int heads) {
+                                                        unsigned short* __restrict__ wp3_out, int C, int heads, int log_temperature) {
     const int hd = blockIdx.x, b = blockIdx.y;
     const int c = C / heads;
     const int NT = (C + 15) >> 4;
@@ -237,7 +237,7 @@ __global__ void __launch_bounds__(256) attn_fold_kernel(const float* __restrict_
     // 2. cosine similarity * temperature, softmax over j (F.normalize clamps the norm at 1e-12)
     if (threadIdx.x < c) {
         const int ii = threadIdx.x;
-        const float T = temperature[hd];
+        const float T = log_temperature ? expf(temperature[hd]) : temperature[hd];
         const float rq = 1.0f / fmaxf(sqrtf(nq[ii]), 1e-12f);
         float m = -INFINITY;
         for (int jj = 0; jj < c; ++jj) {
@@ -277,10 +277,10 @@ __global__ void __launch_bounds__(256) attn_fold_kernel(const float* __restrict_
 }
 
 int launch_attn_fold(const float* partial, int nslab, const float* temperature, const float* w_out,
-                     float* wp_out, void* wp3_out, int B, int C, int heads, hipStream_t st) {
+                     float* wp_out, void* wp3_out, int B, int C, int heads, hipStream_t st, int log_temperature) {
     RF_CHECK_ARG(C % heads == 0 && C / heads <= 64 && C % 4 == 0, "attn_fold: unsupported C=%d heads=%d", C, heads);
     ProfScope prof(st, "attn_fold_kernel", 0.0, 0.0);
-    attn_fold_kernel<<<dim3((unsigned)heads, (unsigned)B), 256, 0, st>>>(partial, nslab, temperature, w_out, wp_out, (unsigned short*)wp3_out, C, heads);
+    attn_fold_kernel<<<dim3((unsigned)heads, (unsigned)B), 256, 0, st>>>(partial, nslab, temperature, w_out, wp_out, (unsigned short*)wp3_out, C, heads, log_temperature);
     return check_launch("attn_fold");
 }
 

@@ -87,7 +87,7 @@ int run_transformer(const TbParams& p, const float* in, float* out, float* ws, c
         av.x1 = bufB + (size_t)2 * C * Pn; av.x1_bstride = (int64_t)3 * C * Pn;
         }
     }
-    RF_TRY(launch_attn_fold(partial, nslab, p.temperature, p.proj_w, wfold, wfold3, B, C, heads, st));
+    RF_TRY(launch_attn_fold(partial, nslab, p.temperature, p.proj_w, wfold, wfold3, B, C, heads, st, p.log_temperature));
     av.C1 = C;
     av.wp = wfold; av.wp_bstride = (int64_t)packed1x1_floats(C, C);
     av.wp3 = wfold3; av.wp3_bstride = (int64_t)packed1x1_b3_floats(C, C);

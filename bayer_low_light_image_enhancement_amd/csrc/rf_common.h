@@ -171,7 +171,7 @@ struct Conv3x3Args {
     float* out;
     int64_t out_bstride;
     int B, Cin, Cout, h, w;
-    int act;               // 0 none, 1 LeakyReLU(0.2), 2 ReLU
+    int act;               // 0 none, 1 LeakyReLU(0.2), 2 ReLU, 3 GELU, 4 tanh (EnhancedBayerProcessor, BayerTORGBColorMultiLvl.py:86-98)
     int store;             // 0 plain, 1 pixel-unshuffle, 2 pixel-shuffle
     int unshuffle_in;      // read the input through the Bayer pack (a1)
     int clamp_in;          // clamp input to [0,1] while loading
@@ -213,7 +213,8 @@ int gram_plan(int B, int C, int heads, int P, int* nslab, int* slab, size_t* par
 int launch_gram(const GramArgs& a, hipStream_t st);
 // softmax + fold into project_out: wp_out[b] = pack(W_out * blockdiag(attn_b))
 int launch_attn_fold(const float* partial, int nslab, const float* temperature, const float* w_out,
-                     float* wp_out, void* wp3_out /* b3 form too, or nullptr */, int B, int C, int heads, hipStream_t st);
+                     float* wp_out, void* wp3_out /* b3 form too, or nullptr */, int B, int C, int heads, hipStream_t st,
+                     int log_temperature = 0);
 
 // ---- fused transformer-block kernels for C = 32 / 64 (rf_fused.hip)
 bool fused_ffn_supported(int C, int hidden, int h, int w);
@@ -236,6 +237,7 @@ struct TbParams {
     const float *qkv_wp /* packed */, *qkv_b, *qkv_dw_w, *qkv_dw_b, *proj_w /* raw [C][C] */, *proj_b;
     const float *ln2_w, *ln2_b, *pw1_wp /* packed */, *pw1_b, *dw_w, *dw_b, *pw2_wp /* packed */, *pw2_b;
     const void *qkv_wp3, *pw1_wp3, *pw2_wp3;   // b3 forms of the three packed weights (nullptr: f32 kernels only)
+    int log_temperature;                       // `temperature` holds log T (TrueColorRawFormer, BayerTORGBColorMultiLvl.py:331,344)
 };
 struct TbBufOffsets { size_t bufA, bufB, x1, partial, wfold, wfold3; };   // float offsets into one scratch area
 size_t transformer_scratch_floats(int B, int C, int heads, int hc, int h, int w, TbBufOffsets* o);
@@ -247,6 +249,19 @@ int launch_rfft2_polar(const float* in, float* mag, float* pha, float2* cscratch
 int launch_polar_irfft2(const float* mag, const float* pha, const float* res, float* out, float2* cscratch, int planes, int h, int w,
                         float lim, hipStream_t st);
 int launch_clamp(const float* in, float* out, size_t n, float lo, float hi, hipStream_t st);
+
+// ---- TrueColorRawFormer extras (rf_truecolor.hip)
+size_t tc_front_scratch_floats(int B, int H, int W, int levels);
+int launch_tc_front(const float* in, int mosaic, const float* wb_gains, const float* color_matrix, const float* wp_c0, const float* b_c0,
+                    const float* wp_c2, const float* b_c2, const float* wp_d0, const float* b_d0, const float* wp_d2, const float* b_d2,
+                    float* scratch, int B, int H, int W, int levels, hipStream_t st);
+int launch_tc_guide_level(const float* scratch, float* guide, int B, int H, int W, int levels, int hf, int wf, hipStream_t st);
+int tc_front_outputs(const float* scratch, const float** y, const float** crcb, const float** rgb, int B, int H, int W, int levels);
+int tc_nblk(int h, int w);
+int launch_tc_spatial(const float* feat, float* xs, const float* guide, const float* w_col, const float* b_col, const float* w_low,
+                      const float* b_low, const float* w_high, const float* b_high, int B, int C, int h, int w, hipStream_t st);
+int launch_tc_residual(const float* xs, const float* r, float* x2, float* partial, int B, int C, int h, int w, hipStream_t st);
+int launch_tc_color_head(float* x, const float* const* prm, int B, size_t P, hipStream_t st);
 
 // ---- FLCA (rf_flca.hip)
 size_t guidance_scratch_floats(int B, int H, int W);

@@ -258,6 +258,8 @@ __global__ void __launch_bounds__(64 * NWV, (NWV >= 8 || NCO >= 3) ? 1 : 2) conv
                 float u = (g == 0 ? (mm[0][r] + s12) + s34 : g == 1 ? fmaf(2.f, d34, d12) : g == 2 ? fmaf(4.f, s34, s12) : fmaf(8.f, d34, d12) + mm[5][r]) + bs;
                 if (a.act == 1) u = u > 0.f ? u : 0.2f * u;
                 else if (a.act == 2) u = fmaxf(u, 0.f);
+                else if (a.act == 3) u = gelu_fast(u);
+                else if (a.act == 4) u = 1.0f - 2.0f * __builtin_amdgcn_rcpf(1.0f + __expf(2.0f * u));      // tanh
                 if (a.clamp_out) u = fminf(fmaxf(u, 0.f), 1.f);
                 v[r][g] = u;
             }

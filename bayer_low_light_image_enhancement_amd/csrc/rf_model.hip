@@ -75,7 +75,29 @@ void add_pack(rf_handle* h, const std::string& name, PackKind kind) {
 void add_stage(rf_handle* h, int i, int C, int heads) {
     const rf_config& cfg = h->cfg;
     const std::string pre = "conv_tran" + std::to_string(i) + ".";
-    if (cfg.variant == RF_VARIANT_FLCA) {
+    if (cfg.variant == RF_VARIANT_TRUECOLOR) {
+        // EnhancedFLCA (BayerTORGBColorMultiLvl.py:192-231), state_dict order
+        const std::string f = pre + "FLCA.";
+        const int hid = C / 8 > 8 ? C / 8 : 8;
+        add_param(h, f + "color_attention.0.weight", {C, 5, 3, 3});
+        add_param(h, f + "color_attention.0.bias", {C});
+        add_param(h, f + "low_attn.0.weight", {C, 1, 3, 3});
+        add_param(h, f + "low_attn.0.bias", {C});
+        add_param(h, f + "high_attn.0.weight", {C, 1, 3, 3});
+        add_param(h, f + "high_attn.0.bias", {C});
+        add_param(h, f + "se.1.weight", {hid, C, 1, 1});
+        add_param(h, f + "se.1.bias", {hid});
+        add_param(h, f + "se.3.weight", {C, hid, 1, 1});
+        add_param(h, f + "se.3.bias", {C});
+        add_param(h, f + "res_proj.0.weight", {C, C, 1, 1});
+        add_param(h, f + "res_proj.0.bias", {C});
+        add_param(h, f + "res_proj.2.weight", {C, C, 1, 1});
+        add_param(h, f + "res_proj.2.bias", {C});
+        for (const char* n : {"res_proj.0.weight", "res_proj.2.weight"}) {
+            add_pack(h, f + n, PK_1x1);
+            add_pack(h, f + n, PK_1x1_B3);
+        }
+    } else if (cfg.variant == RF_VARIANT_FLCA) {
         const std::string f = pre + "FLCA.";
         const int hid = C / 8 > 8 ? C / 8 : 8;
         add_param(h, f + "alpha", {});
@@ -97,7 +119,7 @@ void add_stage(rf_handle* h, int i, int C, int heads) {
     const int hc = C * cfg.ffn_expansion;
     add_param(h, t + "norm1.body.weight", {C});
     add_param(h, t + "norm1.body.bias", {C});
-    add_param(h, t + "attn.temperature", {heads, 1, 1});
+    add_param(h, t + (cfg.variant == RF_VARIANT_TRUECOLOR ? "attn.log_temperature" : "attn.temperature"), {heads, 1, 1});
     add_param(h, t + "attn.qkv.weight", {3 * C, C, 1, 1});
     add_param(h, t + "attn.qkv.bias", {3 * C});
     add_param(h, t + "attn.qkv_dwconv.weight", {3 * C, 1, 3, 3});
@@ -122,7 +144,7 @@ void add_stage(rf_handle* h, int i, int C, int heads) {
     add_pack(h, t + "attn.qkv.weight", PK_1x1_B3);          // b3 forms for the bf16x3 GEMM kernels (rf_common.h)
     add_pack(h, t + "ffn.pointwise1.weight", PK_1x1_B3);
     add_pack(h, t + "ffn.pointwise2.weight", PK_1x1_B3);
-    if (cfg.variant != RF_VARIANT_FLCA) {
+    if (cfg.variant == RF_VARIANT_PLAIN) {
         add_pack(h, pre + "channel_reduce.weight", PK_1x1);
         add_pack(h, pre + "channel_reduce.weight", PK_1x1_B3);
     }
@@ -138,6 +160,7 @@ struct Plan {
     size_t total = 0;
     size_t gscratch, guide[4], skip[3], tA, tB, tU, bufA, bufB, x1, trans, xs, cr;
     size_t gram_partial, wfold_attn, wfold_cr, wfold_attn3, wfold_cr3, flca_partial, ch;
+    int guide_planes;
 };
 
 size_t take(Plan& p, size_t floats) {
@@ -149,8 +172,11 @@ size_t take(Plan& p, size_t floats) {
 int make_plan(const rf_handle* h, int B, int H, int W, Plan& p) {
     const rf_config& c = h->cfg;
     const size_t U0 = (size_t)B * c.dim * H * W;   // floats of a level-0 activation
-    p.gscratch = take(p, guidance_scratch_floats(B, H, W));
-    for (int l = 0; l < 4; ++l) p.guide[l] = take(p, (size_t)B * 4 * (H >> l) * (W >> l));
+    const bool tc = c.variant == RF_VARIANT_TRUECOLOR;
+    const int levels = c.flca_levels > 0 ? c.flca_levels : 2;
+    p.guide_planes = tc ? 7 : 4;
+    p.gscratch = take(p, tc ? tc_front_scratch_floats(B, H, W, levels) : guidance_scratch_floats(B, H, W));
+    for (int l = 0; l < 4; ++l) p.guide[l] = take(p, (size_t)B * p.guide_planes * (H >> l) * (W >> l));
     for (int l = 0; l < 3; ++l) p.skip[l] = take(p, U0 >> l);
     p.tA = take(p, U0);
     p.tB = take(p, U0);
@@ -187,7 +213,7 @@ int make_plan(const rf_handle* h, int B, int H, int W, Plan& p) {
         const size_t a3 = (size_t)B * packed1x1_b3_floats(C, C), cr3 = (size_t)B * packed1x1_b3_floats(2 * C, C);
         if (a3 > wa3) wa3 = a3;
         if (cr3 > wc3) wc3 = cr3;
-        const size_t f = (size_t)B * flca_nblk(H >> l, W >> l) * C;
+        const size_t f = (size_t)B * (tc ? tc_nblk(H >> l, W >> l) : flca_nblk(H >> l, W >> l)) * C;
         if (f > fp) fp = f;
     }
     p.gram_partial = take(p, gp);
@@ -219,7 +245,8 @@ int run_stage(const rf_handle* h, int i, int lvl, const float* in, float* out, f
 
     // TransformerBlock: x + attn(LN1(x)), then x + ffn(LN2(x))  (rf_block.hip)
     TbParams tp{};
-    tp.ln1_w = P(h, t + "norm1.body.weight"); tp.ln1_b = P(h, t + "norm1.body.bias"); tp.temperature = P(h, t + "attn.temperature");
+    tp.ln1_w = P(h, t + "norm1.body.weight"); tp.ln1_b = P(h, t + "norm1.body.bias");
+    if (cfg.variant != RF_VARIANT_TRUECOLOR) tp.temperature = P(h, t + "attn.temperature");
     tp.qkv_wp = PK(h, t + "attn.qkv.weight"); tp.qkv_b = P(h, t + "attn.qkv.bias");
     tp.qkv_dw_w = P(h, t + "attn.qkv_dwconv.weight"); tp.qkv_dw_b = P(h, t + "attn.qkv_dwconv.bias");
     tp.proj_w = P(h, t + "attn.project_out.weight"); tp.proj_b = P(h, t + "attn.project_out.bias");
@@ -228,6 +255,7 @@ int run_stage(const rf_handle* h, int i, int lvl, const float* in, float* out, f
     tp.dw_w = P(h, t + "ffn.depthwise.weight"); tp.dw_b = P(h, t + "ffn.depthwise.bias");
     tp.pw2_wp = PK(h, t + "ffn.pointwise2.weight"); tp.pw2_b = P(h, t + "ffn.pointwise2.bias");
     tp.qkv_wp3 = PK3(h, t + "attn.qkv.weight"); tp.pw1_wp3 = PK3(h, t + "ffn.pointwise1.weight"); tp.pw2_wp3 = PK3(h, t + "ffn.pointwise2.weight");
+    if (cfg.variant == RF_VARIANT_TRUECOLOR) { tp.temperature = P(h, t + "attn.log_temperature"); tp.log_temperature = 1; }
     TbBufOffsets to{p.bufA, p.bufB, p.x1, p.gram_partial, p.wfold_attn, p.wfold_attn3};
     RF_TRY(run_transformer(tp, in, trans, ws, to, B, C, heads, hc, hh, ww, st));
 
@@ -237,7 +265,29 @@ int run_stage(const rf_handle* h, int i, int lvl, const float* in, float* out, f
     r.x2 = trans; r.C2 = C; r.x2_bstride = (int64_t)C * Pn;
     r.bias = P(h, pre + "channel_reduce.bias");
     r.out = crb; r.out_bstride = (int64_t)C * Pn; r.Cout = C; r.B = B; r.P = Pn; r.w = ww;
-    if (cfg.variant == RF_VARIANT_FLCA) {
+    if (cfg.variant == RF_VARIANT_TRUECOLOR) {
+        // EnhancedFLCA (BayerTORGBColorMultiLvl.py:249-293): spatial gate -> x + 0.2 tanh(res_proj(x)) -> squeeze-excite (folded
+        // into channel_reduce like the FLCA variant's)
+        const std::string f = pre + "FLCA.";
+        RF_TRY(launch_tc_spatial(in, xs, ws + p.guide[lvl], P(h, f + "color_attention.0.weight"), P(h, f + "color_attention.0.bias"),
+                                 P(h, f + "low_attn.0.weight"), P(h, f + "low_attn.0.bias"), P(h, f + "high_attn.0.weight"),
+                                 P(h, f + "high_attn.0.bias"), B, C, hh, ww, st));
+        Conv1x1Args r0{};
+        r0.x1 = xs; r0.C1 = C; r0.x1_bstride = (int64_t)C * Pn; r0.wp = PK(h, f + "res_proj.0.weight"); r0.wp3 = PK3(h, f + "res_proj.0.weight");
+        r0.bias = P(h, f + "res_proj.0.bias"); r0.out = crb; r0.out_bstride = (int64_t)C * Pn; r0.Cout = C; r0.B = B; r0.P = Pn; r0.w = ww; r0.act = 2;
+        RF_TRY(launch_conv1x1(r0, st));
+        Conv1x1Args r2 = r0;
+        r2.x1 = crb; r2.wp = PK(h, f + "res_proj.2.weight"); r2.wp3 = PK3(h, f + "res_proj.2.weight"); r2.bias = P(h, f + "res_proj.2.bias");
+        r2.out = ws + p.bufA; r2.act = 0;
+        RF_TRY(launch_conv1x1(r2, st));
+        RF_TRY(launch_tc_residual(xs, ws + p.bufA, xs, ws + p.flca_partial, B, C, hh, ww, st));
+        const int hid = C / 8 > 8 ? C / 8 : 8;
+        RF_TRY(launch_flca_se_fold(ws + p.flca_partial, tc_nblk(hh, ww), Pn, P(h, f + "se.1.weight"), P(h, f + "se.1.bias"),
+                                   P(h, f + "se.3.weight"), P(h, f + "se.3.bias"), hid, P(h, pre + "channel_reduce.weight"),
+                                   ws + p.wfold_cr, ws + p.wfold_cr3, ws + p.ch, B, C, st));
+        r.wp = ws + p.wfold_cr; r.wp_bstride = (int64_t)packed1x1_floats(2 * C, C);
+        r.wp3 = ws + p.wfold_cr3; r.wp3_bstride = (int64_t)packed1x1_b3_floats(2 * C, C);
+    } else if (cfg.variant == RF_VARIANT_FLCA) {
         const std::string f = pre + "FLCA.";
         FlcaSpatialArgs s{};
         s.feat = in; s.xs = xs; s.guide = ws + p.guide[lvl];
@@ -278,7 +328,10 @@ int rf_create(const rf_config* cfg, rf_handle** out) {
     RF_CHECK_ARG(cfg->dim > 0 && cfg->dim % 8 == 0, "rf_create: dim=%d must be a positive multiple of 8", cfg->dim);
     RF_CHECK_ARG(cfg->inp_channels == 1, "rf_create: inp_channels=%d (only the 1-channel Bayer mosaic is supported)", cfg->inp_channels);
     RF_CHECK_ARG(cfg->out_channels > 0 && cfg->ffn_expansion > 0, "rf_create: bad out_channels / ffn_expansion");
-    RF_CHECK_ARG(cfg->variant == RF_VARIANT_FLCA || cfg->variant == RF_VARIANT_PLAIN, "rf_create: unknown variant %d", cfg->variant);
+    RF_CHECK_ARG(cfg->variant == RF_VARIANT_FLCA || cfg->variant == RF_VARIANT_PLAIN || cfg->variant == RF_VARIANT_TRUECOLOR,
+                 "rf_create: unknown variant %d", cfg->variant);
+    RF_CHECK_ARG(cfg->flca_levels >= 0 && cfg->flca_levels <= 3, "rf_create: flca_levels=%d (1..3, 0 = default 2)", cfg->flca_levels);
+    RF_CHECK_ARG(cfg->variant != RF_VARIANT_TRUECOLOR || cfg->out_channels == 3, "rf_create: the TrueColor colour head is defined for 3 output channels");
     for (int l = 0; l < 4; ++l) {
         const int C = cfg->dim << l;
         RF_CHECK_ARG(cfg->heads[l] > 0 && C % cfg->heads[l] == 0 && C / cfg->heads[l] <= 64,
@@ -290,6 +343,20 @@ int rf_create(const rf_config* cfg, rf_handle** out) {
     rf_handle* h = new rf_handle();
     h->cfg = *cfg;
     const int d = cfg->dim;
+    if (cfg->variant == RF_VARIANT_TRUECOLOR) {   // EnhancedBayerProcessor (BayerTORGBColorMultiLvl.py:73-98), state_dict order
+        add_param(h, "bayer_processor.wb_gains", {4});
+        add_param(h, "bayer_processor.color_matrix", {3, 4});
+        add_param(h, "bayer_processor.demosaic_refine.0.weight", {32, 3, 3, 3});
+        add_param(h, "bayer_processor.demosaic_refine.0.bias", {32});
+        add_param(h, "bayer_processor.demosaic_refine.2.weight", {3, 32, 3, 3});
+        add_param(h, "bayer_processor.demosaic_refine.2.bias", {3});
+        add_param(h, "bayer_processor.chroma_extractor.0.weight", {16, 4, 3, 3});
+        add_param(h, "bayer_processor.chroma_extractor.0.bias", {16});
+        add_param(h, "bayer_processor.chroma_extractor.2.weight", {2, 16, 3, 3});
+        add_param(h, "bayer_processor.chroma_extractor.2.bias", {2});
+        for (const char* n : {"demosaic_refine.0.weight", "demosaic_refine.2.weight", "chroma_extractor.0.weight", "chroma_extractor.2.weight"})
+            add_pack(h, std::string("bayer_processor.") + n, PK_3x3);
+    }
     add_param(h, "embedding.weight", {d, 4 * cfg->inp_channels, 3, 3});
     add_param(h, "embedding.bias", {d});
     add_pack(h, "embedding.weight", PK_3x3);
@@ -317,6 +384,17 @@ int rf_create(const rf_config* cfg, rf_handle** out) {
     add_param(h, "conv_out.weight", {4 * cfg->out_channels, d, 3, 3});
     add_param(h, "conv_out.bias", {4 * cfg->out_channels});
     add_pack(h, "conv_out.weight", PK_3x3);
+    if (cfg->variant == RF_VARIANT_TRUECOLOR) {   // CameraAwareColorCorrection (BayerTORGBColorMultiLvl.py:139-158)
+        add_param(h, "color_correction.gamma_param", {});
+        add_param(h, "color_correction.color_transform.0.weight", {64, 3, 1, 1});
+        add_param(h, "color_correction.color_transform.0.bias", {64});
+        add_param(h, "color_correction.color_transform.2.weight", {3, 64, 1, 1});
+        add_param(h, "color_correction.color_transform.2.bias", {3});
+        add_param(h, "color_correction.tone_curve.0.weight", {32, 1, 1, 1});
+        add_param(h, "color_correction.tone_curve.0.bias", {32});
+        add_param(h, "color_correction.tone_curve.2.weight", {1, 32, 1, 1});
+        add_param(h, "color_correction.tone_curve.2.bias", {1});
+    }
     *out = h;
     return RF_OK;
 }
@@ -410,6 +488,7 @@ int rf_forward_stage(rf_handle* h, int stage, const float* in, const float* pack
     RF_CHECK_ARG(B > 0 && B <= 65535 && H > 0 && W > 0 && H % 8 == 0 && W % 8 == 0,
                  "rf_forward_stage: packed size %dx%d must be positive multiples of 8", H, W);
     RF_CHECK_ARG(h->cfg.variant != RF_VARIANT_FLCA || packed, "rf_forward_stage: the FLCA branch needs the packed frame for its guidance");
+    RF_CHECK_ARG(h->cfg.variant != RF_VARIANT_TRUECOLOR, "rf_forward_stage: not available for the TrueColor variant");
     if (!h->packed) {
         set_error("rf_forward_stage: parameters not packed (call rf_pack_params after rf_set_param)");
         return RF_E_MISSING;
@@ -454,10 +533,21 @@ int rf_forward(rf_handle* h, const float* in, float* out, void* workspace, size_
     const int d = cfg.dim;
     const int mosaic = packed_input ? 0 : 1;
 
+    const int levels = cfg.flca_levels > 0 ? cfg.flca_levels : 2;
     if (cfg.variant == RF_VARIANT_FLCA) {
         RF_TRY(launch_guidance_base(in, mosaic, cfg.clamp_io, ws + p.gscratch, B, H, W, st));
         for (int l = 0; l < 4; ++l)
             RF_TRY(launch_guidance_level(ws + p.gscratch, ws + p.guide[l], B, H, W, H >> l, W >> l, st));
+    } else if (cfg.variant == RF_VARIANT_TRUECOLOR) {
+        const std::string bp = "bayer_processor.";
+        RF_TRY(launch_tc_front(in, mosaic, P(h, bp + "wb_gains"), P(h, bp + "color_matrix"),
+                               PK(h, bp + "chroma_extractor.0.weight"), P(h, bp + "chroma_extractor.0.bias"),
+                               PK(h, bp + "chroma_extractor.2.weight"), P(h, bp + "chroma_extractor.2.bias"),
+                               PK(h, bp + "demosaic_refine.0.weight"), P(h, bp + "demosaic_refine.0.bias"),
+                               PK(h, bp + "demosaic_refine.2.weight"), P(h, bp + "demosaic_refine.2.bias"),
+                               ws + p.gscratch, B, H, W, levels, st));
+        for (int l = 0; l < 4; ++l)
+            RF_TRY(launch_tc_guide_level(ws + p.gscratch, ws + p.guide[l], B, H, W, levels, H >> l, W >> l, st));
     }
     // embedding (reads the mosaic through the Bayer pack)
     Conv3x3Args e{};
@@ -510,7 +600,15 @@ int rf_forward(rf_handle* h, const float* in, float* out, void* workspace, size_
     o.x = ws + p.tB; o.x_bstride = (int64_t)d * H * W; o.wp = PK(h, "conv_out.weight"); o.bias = P(h, "conv_out.bias");
     o.out = out; o.out_bstride = (int64_t)cfg.out_channels * 4 * H * W;
     o.B = B; o.Cin = d; o.Cout = 4 * cfg.out_channels; o.h = H; o.w = W; o.act = 1; o.store = 2; o.clamp_out = cfg.clamp_io;
+    if (cfg.variant == RF_VARIANT_TRUECOLOR) o.act = 2;      // F.relu before the PixelShuffle (BayerTORGBColorMultiLvl.py:458)
     RF_TRY(launch_conv3x3(o, st));
+    if (cfg.variant == RF_VARIANT_TRUECOLOR) {
+        const std::string cc = "color_correction.";
+        const float* prm[9] = {P(h, cc + "gamma_param"), P(h, cc + "color_transform.0.weight"), P(h, cc + "color_transform.0.bias"),
+                               P(h, cc + "color_transform.2.weight"), P(h, cc + "color_transform.2.bias"), P(h, cc + "tone_curve.0.weight"),
+                               P(h, cc + "tone_curve.0.bias"), P(h, cc + "tone_curve.2.weight"), P(h, cc + "tone_curve.2.bias")};
+        RF_TRY(launch_tc_color_head(out, prm, B, (size_t)4 * H * W, st));
+    }
     return RF_OK;
 }
 

@@ -10,8 +10,10 @@ Interface kept from the reference:
   ``module.`` prefix left by ``nn.DataParallel`` is stripped, test.py:90);
 * ``forward(x[B,1,2H,2W]) -> [B,3,2H,2W]`` float32, input not modified (test.py:116).
 
-``variant='flca'`` is the wiring of FrequencyawareLumaChromaAttentionRAWFormer.py:284-370
-(the only whole model of the reference that runs); ``variant='plain'`` replaces the FLCA
+``variant='flca'`` is the wiring of FrequencyawareLumaChromaAttentionRAWFormer.py:284-370;
+``variant='truecolor'`` is ``TrueColorRawFormer`` (BayerTORGBColorMultiLvl.py:387-462: learned Bayer
+front end, colour-aware pyramid FLCA, ``exp(log_temperature)`` attention, colour-correction head;
+``flca_levels`` as in its constructor); ``variant='plain'`` replaces the FLCA
 branch by the 3x3 conv branch of RawFomer_WFB_FFAB/model.py:393-412 (``branch_lrelu=True``)
 or model.py:94-108 (``False``) and, with ``clamp_io=True``, adds the I/O clamps of
 RawFomer_WFB_FFAB/model.py:475,508.
@@ -99,7 +101,7 @@ class _DeviceState:
 class RawFormer(nn.Module):
     def __init__(self, inp_channels: int = 1, out_channels: int = 3, dim: int = 48,
                  num_heads: Sequence[int] = (8, 8, 8, 8), ffn_expansion_factor: int = 2, *,
-                 variant: str = "flca", branch_lrelu: bool = True, clamp_io: bool = False,
+                 variant: str = "flca", branch_lrelu: bool = True, clamp_io: bool = False, flca_levels: int = 2,
                  in_ch: Optional[int] = None, out_ch: Optional[int] = None,
                  heads: Optional[Sequence[int]] = None, ffn_exp: Optional[int] = None):
         super().__init__()
@@ -107,13 +109,14 @@ class RawFormer(nn.Module):
         out_channels = out_ch if out_ch is not None else out_channels
         num_heads = list(heads if heads is not None else num_heads)
         ffn_expansion_factor = ffn_exp if ffn_exp is not None else ffn_expansion_factor
-        if variant not in ("flca", "plain"):
-            raise ValueError(f"variant must be 'flca' or 'plain', got {variant!r}")
+        if variant not in ("flca", "plain", "truecolor"):
+            raise ValueError(f"variant must be 'flca', 'plain' or 'truecolor', got {variant!r}")
         if len(num_heads) != 4:
             raise ValueError("num_heads must have 4 entries")
         self.dim, self.inp_channels, self.out_channels = int(dim), int(inp_channels), int(out_channels)
         self.num_heads, self.ffn_expansion_factor = [int(h) for h in num_heads], int(ffn_expansion_factor)
         self.variant, self.branch_lrelu, self.clamp_io = variant, bool(branch_lrelu), bool(clamp_io)
+        self.flca_levels = int(flca_levels)
 
         cfg = self._config()
         lib = _lib.load()
@@ -129,10 +132,13 @@ class RawFormer(nn.Module):
                 self._register(key, nn.Parameter(torch.empty(tuple(shape[: ndim.value]), dtype=torch.float32)))
         finally:
             lib.rf_destroy(probe)
-        if variant == "flca":
+        if variant in ("flca", "truecolor"):
             # fixed buffers the reference keeps in its state_dict (values are constants in the kernels)
-            for k, v in (("r_w", 0.299), ("g_w", 0.587), ("b_w", 0.114)):
-                self._register_buffer("luma_chroma." + k, torch.tensor(v, dtype=torch.float32))
+            if variant == "flca":
+                for k, v in (("r_w", 0.299), ("g_w", 0.587), ("b_w", 0.114)):
+                    self._register_buffer("luma_chroma." + k, torch.tensor(v, dtype=torch.float32))
+            else:
+                self._register_buffer("bayer_processor.y_weights", torch.tensor([0.2126, 0.7152, 0.0722], dtype=torch.float32))
             hv = torch.tensor([1.0, 1.0]) / math.sqrt(2.0)
             gv = torch.tensor([1.0, -1.0]) / math.sqrt(2.0)
             filt = torch.stack([torch.outer(hv, hv), torch.outer(hv, gv), torch.outer(gv, hv), torch.outer(gv, gv)]).unsqueeze(1)
@@ -147,8 +153,8 @@ class RawFormer(nn.Module):
     def _config(self) -> _lib.RfConfig:
         return _lib.RfConfig(self.dim, (C.c_int32 * 4)(*self.num_heads), self.inp_channels, self.out_channels,
                              self.ffn_expansion_factor,
-                             _lib.RF_VARIANT_FLCA if self.variant == "flca" else _lib.RF_VARIANT_PLAIN,
-                             int(self.branch_lrelu), int(self.clamp_io))
+                             {"flca": _lib.RF_VARIANT_FLCA, "plain": _lib.RF_VARIANT_PLAIN, "truecolor": _lib.RF_VARIANT_TRUECOLOR}[self.variant],
+                             int(self.branch_lrelu), int(self.clamp_io), self.flca_levels)
 
     def _node(self, path: List[str]) -> nn.Module:
         mod: nn.Module = self
@@ -174,6 +180,14 @@ class RawFormer(nn.Module):
             leaf = key.rsplit(".", 1)[-1]
             if leaf in ("alpha", "beta", "gamma", "temperature"):
                 p.fill_(1.0)
+            elif leaf == "log_temperature":                    # TrueColorRawFormer's own initial values
+                p.zero_()                                      # (BayerTORGBColorMultiLvl.py:78-83, 144, 331)
+            elif leaf == "wb_gains":
+                p.copy_(torch.tensor([1.8, 1.0, 1.0, 1.6]))
+            elif leaf == "color_matrix":
+                p.copy_(torch.eye(3, 4))
+            elif leaf == "gamma_param":
+                p.fill_(2.2)
             elif p.dim() == 1:
                 if leaf == "weight":
                     p.fill_(1.0)                      # LayerNorm scale

@@ -60,8 +60,14 @@ def param_values(seed: int, name: str, shape) -> np.ndarray:
     """
     shape = tuple(int(s) for s in shape)
     leaf = name.rsplit(".", 1)[-1]
-    if leaf in ("r_w", "g_w", "b_w", "filt"):
+    if leaf in ("r_w", "g_w", "b_w", "filt", "y_weights"):
         raise ValueError(f"{name} is a fixed buffer, not a generated parameter")
+    if leaf == "wb_gains":          # TrueColorRawFormer front end (BayerTORGBColorMultiLvl.py:78-83): camera-like values
+        return uniform(seed, name, shape, 0.5, 2.0)
+    if leaf == "color_matrix":      # [3, 4] = 3x3 matrix near identity | bias column
+        return (np.eye(3, 4, dtype=np.float32) + uniform(seed, name, shape, -0.1, 0.1)).astype(np.float32)
+    if leaf == "gamma_param":
+        return uniform(seed, name, shape, 1.5, 2.5)
     if leaf in ("alpha", "beta", "gamma"):
         return uniform(seed, name, shape, 0.5, 1.5)
     if leaf == "running_var":  # BatchNorm statistics must stay positive
@@ -87,7 +93,7 @@ def fill_state_dict(state_dict, seed: int):
 
     for name, t in state_dict.items():
         leaf = name.rsplit(".", 1)[-1]
-        if leaf in ("r_w", "g_w", "b_w", "filt") or not t.dtype.is_floating_point:
+        if leaf in ("r_w", "g_w", "b_w", "filt", "y_weights") or not t.dtype.is_floating_point:
             continue
         v = param_values(seed, name, tuple(t.shape))
         with torch.no_grad():

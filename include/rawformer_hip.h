@@ -37,6 +37,9 @@ extern "C" {
 
 #define RF_VARIANT_FLCA 0    /* FrequencyawareLumaChromaAttentionRAWFormer.py:257-278 branch */
 #define RF_VARIANT_PLAIN 1   /* conv branch: RawFomer_WFB_FFAB/model.py:393-412, model.py:94-108 */
+#define RF_VARIANT_TRUECOLOR 2 /* TrueColorRawFormer, BayerTORGBColorMultiLvl.py:387-462: learned Bayer front end
+                                  (EnhancedBayerProcessor), EnhancedFLCA branch, exp(log_temperature) attention, ReLU before
+                                  the PixelShuffle, CameraAwareColorCorrection head */
 
 typedef struct rf_handle rf_handle;
 
@@ -49,6 +52,7 @@ typedef struct rf_config {
     int32_t variant;          /* RF_VARIANT_*                                         */
     int32_t branch_lrelu;     /* plain variant: LeakyReLU on the conv branch (WFB) or not (model.py) */
     int32_t clamp_io;         /* clamp input and output to [0,1]: RawFomer_WFB_FFAB/model.py:475,508 */
+    int32_t flca_levels;      /* TRUECOLOR: wavelet pyramid depth of EnhancedFLCA (reference default 2; 0 = 2) */
 } rf_config;
 
 const char* rf_last_error(void);

@@ -494,6 +494,44 @@ def ffab(blocks_mod, wfb_ns):
     save("ffab", **out)
 
 
+TRUECOLOR_CASES = (("tc_d16_b2_32x48", 16, 2, 32, 48, 81), ("tc_d32_b1_64x64", 32, 1, 64, 64, 82))
+
+
+def truecolor():
+    """f4: ``TrueColorRawFormer`` (BayerTORGBColorMultiLvl.py:387-462, imports with torch + einops only): whole-model outputs
+    at small sizes in full, and one 4x128x128 packed frame (BASELINE configs[0] shape) as samples + channel statistics."""
+    sys.path.insert(0, REF)
+    import BayerTORGBColorMultiLvl as T
+    import json
+    out = {}
+    for tag, dim, b, hh, ww, seed in TRUECOLOR_CASES:
+        m = fill(T.TrueColorRawFormer(dim=dim), 4000 + dim)
+        x = t(synth.bayer_mosaic(seed, b, hh, ww))
+        with torch.no_grad():
+            y = m(x)
+            mine = R.truecolor_forward(sd_of(m), x, dim)
+            y64 = m.double()(x.double()).float()       # the reference itself in float64: its float32 noise floor
+            m.float()
+        log(f"  TrueColorRawFormer {tag}: oracle vs reference {maxabs(y, mine):.2e}, reference f32 vs f64 {maxabs(y, y64):.2e}, mean {float(y.mean()):.3f}")
+        assert maxabs(y, mine) < 2e-4
+        out[f"{tag}.out"], out[f"{tag}.out_fp64"] = y, y64
+    m = fill(T.TrueColorRawFormer(dim=32), 4032)
+    x = t(synth.random_mosaic(83, 1, 256, 256))
+    with torch.no_grad():
+        y = m(x)
+        mine = R.truecolor_forward(sd_of(m), x, 32)
+    log(f"  TrueColorRawFormer cfg1 shape (dim 32, 1x256x256 mosaic): oracle vs reference {maxabs(y, mine):.2e}")
+    idx = np.sort(synth.uniform01(84, "tc.idx", 4096) * y.numel()).astype(np.int64)
+    out["cfg1.idx"], out["cfg1.samples"] = idx, y.reshape(-1)[t(idx)]
+    out["cfg1.chan_mean"] = y.double().mean(dim=(0, 2, 3)).float()
+    save("truecolor", **out)
+    keys = {str(d): [[k, list(v.shape)] for k, v in T.TrueColorRawFormer(dim=d).state_dict().items()] for d in (16, 32)}
+    path = os.path.join(GOLD, "truecolor_state_dict_keys.json")
+    with open(path, "w") as f:
+        json.dump(keys, f)
+    log(f"  wrote {os.path.relpath(path, REPO)} ({os.path.getsize(path)} B)")
+
+
 def state_dict_keys(flca_mod):
     """Key names and shapes of the reference's state_dict (what test.py:88-91 loads strictly)."""
     import json
@@ -514,6 +552,7 @@ def main():
     ap.add_argument("--only-harness", action="store_true", help="only the evaluation-harness fixture (test.py helpers)")
     ap.add_argument("--only-attenblock", action="store_true", help="only the Attenblock.LuminanceAwareMHSA (a16) and WFB extras (a17) fixtures")
     ap.add_argument("--only-cfg4", action="store_true", help="only BASELINE config 4 (RawFormer-L, one 2848x4256 mosaic)")
+    ap.add_argument("--only-truecolor", action="store_true", help="only the TrueColorRawFormer fixtures (f4)")
     ap.add_argument("--only-ffab", action="store_true", help="only the FEB / FFAB / rfft2 / WMB-wavelet-branch fixtures (f2)")
     args = ap.parse_args()
     if args.only_keys:
@@ -529,6 +568,13 @@ def main():
         import_reference()
         attenblock()
         wfb_extras()
+        with open(os.path.join(GOLD, "PINNING.txt"), "a") as f:
+            f.write("\n".join(LOG) + "\n")
+        return
+    if args.only_truecolor:
+        os.makedirs(GOLD, exist_ok=True)
+        torch.set_num_threads(8)
+        truecolor()
         with open(os.path.join(GOLD, "PINNING.txt"), "a") as f:
             f.write("\n".join(LOG) + "\n")
         return
@@ -552,6 +598,7 @@ def main():
     attenblock()
     wfb_extras()
     ffab(mods[2], mods[4])
+    truecolor()
     state_dict_keys(mods[0])
     with open(os.path.join(GOLD, "PINNING.txt"), "w") as f:
         f.write("# written by oracle/make_golden.py: reference (run on CPU here) vs oracle/rawformer_ref.py\n")

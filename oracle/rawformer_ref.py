@@ -542,3 +542,97 @@ def wmb_ll_branch(x: Tensor, p: Dict[str, Tensor], pre: str, high=None) -> Tenso
     if high is not None:
         hi = high(hi)
     return t + ((iwt_init(torch.cat((ll, hi), dim=0)) + 1.0) / 2.0).clamp(0.0, 1.0)
+
+
+# ------------------------------------------------------------------------------------------
+# f4: TrueColorRawFormer (BayerTORGBColorMultiLvl.py:387-462), the reference's latest whole model: the same U-Net with
+# a learned Bayer front end, a colour-aware multi-level FLCA branch, exp(log_temperature) attention and a colour head.
+# ------------------------------------------------------------------------------------------
+def enhanced_bayer_processor(x4: Tensor, p: Dict[str, Tensor], pre: str, eps: float = 1e-6):
+    """EnhancedBayerProcessor.forward (BayerTORGBColorMultiLvl.py:100-134) -> y, cr, cb, refined_rgb."""
+    wb = x4 * (F.softplus(p[pre + "wb_gains"]) + 1e-6).view(1, 4, 1, 1)
+    r, g, b = wb[:, 0:1], 0.5 * (wb[:, 1:2] + wb[:, 2:3]), wb[:, 3:4]
+    rgb = torch.cat([r, g, b], dim=1)
+    m = p[pre + "color_matrix"]
+    lin = torch.einsum("bchw,oc->bohw", rgb, m[:, :3]) + m[:, 3].view(1, 3, 1, 1)
+    y = (lin * torch.tensor([0.2126, 0.7152, 0.0722]).view(1, 3, 1, 1)).sum(dim=1, keepdim=True)
+    y = y / y.amax(dim=(2, 3), keepdim=True).clamp_min(eps)
+    c = F.relu(F.conv2d(torch.cat([r, g, b, y], dim=1), p[pre + "chroma_extractor.0.weight"], p[pre + "chroma_extractor.0.bias"], padding=1))
+    c = torch.tanh(F.conv2d(c, p[pre + "chroma_extractor.2.weight"], p[pre + "chroma_extractor.2.bias"], padding=1))
+    d = F.gelu(F.conv2d(lin, p[pre + "demosaic_refine.0.weight"], p[pre + "demosaic_refine.0.bias"], padding=1))
+    d = F.conv2d(d, p[pre + "demosaic_refine.2.weight"], p[pre + "demosaic_refine.2.bias"], padding=1)
+    return y, c[:, 0:1], c[:, 1:2], lin + d
+
+
+def enhanced_flca_guidance(y: Tensor, cr: Tensor, cb: Tensor, rgb: Tensor, size: Tuple[int, int], levels: int = 2, eps: float = 1e-8) -> Tensor:
+    """Guidance planes of EnhancedFLCA at feature size ``size`` (BayerTORGBColorMultiLvl.py:236-275):
+    ``[y, cr, cb, R, G, y_low, y_high]`` -- y_low = LL of the deepest pyramid level, y_high = mean of the resized
+    high-band magnitudes of all levels."""
+    highs, cur = [], y
+    for _ in range(levels):
+        ll, (lh, hl, hh) = haar_dwt(cur)
+        highs.append(torch.sqrt(lh * lh + hl * hl + hh * hh + eps))
+        cur = ll
+    hf = [bilinear_resize(t, size) for t in highs]
+    y_high = torch.stack(hf, dim=0).mean(dim=0) if len(hf) > 1 else hf[0]
+    rs = bilinear_resize(rgb, size)
+    return torch.cat([bilinear_resize(y, size), bilinear_resize(cr, size), bilinear_resize(cb, size), rs[:, 0:1], rs[:, 1:2],
+                      bilinear_resize(cur, size), y_high], dim=1)
+
+
+def enhanced_flca(feat: Tensor, guide, p: Dict[str, Tensor], pre: str, levels: int = 2) -> Tensor:
+    """EnhancedFLCA.forward (BayerTORGBColorMultiLvl.py:249-293)."""
+    g = enhanced_flca_guidance(*guide, feat.shape[-2:], levels)
+    color = torch.sigmoid(F.conv2d(g[:, 0:5], p[pre + "color_attention.0.weight"], p[pre + "color_attention.0.bias"], padding=1))
+    low = torch.sigmoid(F.conv2d(g[:, 5:6], p[pre + "low_attn.0.weight"], p[pre + "low_attn.0.bias"], padding=1))
+    high = torch.tanh(F.conv2d(g[:, 6:7], p[pre + "high_attn.0.weight"], p[pre + "high_attn.0.bias"], padding=1))
+    x = feat * (1.0 + color + torch.tanh(low + high))
+    r = F.conv2d(F.relu(F.conv2d(x, p[pre + "res_proj.0.weight"], p[pre + "res_proj.0.bias"])), p[pre + "res_proj.2.weight"], p[pre + "res_proj.2.bias"])
+    x = x + torch.tanh(r) * 0.2
+    hid = torch.relu(F.conv2d(x.mean(dim=(2, 3), keepdim=True), p[pre + "se.1.weight"], p[pre + "se.1.bias"]))
+    return x * torch.sigmoid(F.conv2d(hid, p[pre + "se.3.weight"], p[pre + "se.3.bias"]))
+
+
+def camera_color_correction(x: Tensor, p: Dict[str, Tensor], pre: str) -> Tensor:
+    """CameraAwareColorCorrection.forward (BayerTORGBColorMultiLvl.py:160-176)."""
+    gamma = F.softplus(p[pre + "gamma_param"]) + 1e-6
+    x = torch.pow(x.clamp(0.0, 1.0), 1.0 / gamma)
+    x = F.conv2d(F.relu(F.conv2d(x, p[pre + "color_transform.0.weight"], p[pre + "color_transform.0.bias"])),
+                 p[pre + "color_transform.2.weight"], p[pre + "color_transform.2.bias"])
+    out = []
+    for i in range(x.shape[1]):
+        ch = x[:, i:i + 1]
+        mod = torch.sigmoid(F.conv2d(F.relu(F.conv2d(ch, p[pre + "tone_curve.0.weight"], p[pre + "tone_curve.0.bias"])),
+                                     p[pre + "tone_curve.2.weight"], p[pre + "tone_curve.2.bias"]))
+        out.append((ch * (0.8 + 0.4 * mod)).clamp(0.0, 1.0))
+    return torch.cat(out, dim=1).clamp(0.0, 1.0)
+
+
+def truecolor_stage(x: Tensor, guide, p: Dict[str, Tensor], pre: str, heads: int, levels: int = 2) -> Tensor:
+    """EnhancedConv_Transformer.forward (BayerTORGBColorMultiLvl.py:371-377)."""
+    tp = dict(p)
+    tp[pre + "Transformer.attn.temperature"] = p[pre + "Transformer.attn.log_temperature"].exp()     # Attention, :344
+    t = F.conv2d(torch.cat([enhanced_flca(x, guide, p, pre + "FLCA.", levels), transformer_block(x, tp, pre + "Transformer.", heads)], dim=1),
+                 p[pre + "channel_reduce.weight"], p[pre + "channel_reduce.bias"])
+    return F.leaky_relu(F.conv2d(t, p[pre + "Conv_out.weight"], p[pre + "Conv_out.bias"], padding=1), 0.2)
+
+
+def truecolor_forward(p: Dict[str, Tensor], x: Tensor, dim: int, heads=(8, 8, 8, 8), levels: int = 2) -> Tensor:
+    """TrueColorRawFormer.forward (BayerTORGBColorMultiLvl.py:421-462); mosaic sizes divisible by 16 (no reflect padding)."""
+    x4 = pixel_unshuffle2(x)
+    guide = enhanced_bayer_processor(x4, p, "bayer_processor.")
+    t = F.conv2d(x4, p["embedding.weight"], p["embedding.bias"], padding=1)
+    e1 = truecolor_stage(t, guide, p, "conv_tran1.", heads[0], levels)
+    e2 = truecolor_stage(downsample(e1, p["down1.body.0.weight"]), guide, p, "conv_tran2.", heads[1], levels)
+    e3 = truecolor_stage(downsample(e2, p["down2.body.0.weight"]), guide, p, "conv_tran3.", heads[2], levels)
+    e4 = truecolor_stage(downsample(e3, p["down3.body.0.weight"]), guide, p, "conv_tran4.", heads[3], levels)
+
+    def up(t_in, skip, i):
+        u = conv_transpose2x2(t_in, p[f"up{i}.weight"], p[f"up{i}.bias"])
+        return F.conv2d(torch.cat([u, skip], dim=1), p[f"channel_reduce{i}.weight"], p[f"channel_reduce{i}.bias"])
+
+    d3 = truecolor_stage(up(e4, e3, 1), guide, p, "conv_tran5.", heads[2], levels)
+    d2 = truecolor_stage(up(d3, e2, 2), guide, p, "conv_tran6.", heads[1], levels)
+    d1 = truecolor_stage(up(d2, e1, 3), guide, p, "conv_tran7.", heads[0], levels)
+    out = pixel_shuffle2(F.relu(F.conv2d(d1, p["conv_out.weight"], p["conv_out.bias"], padding=1)))
+    return camera_color_correction(out, p, "color_correction.")
