@@ -18,6 +18,7 @@ Usage:  python oracle/make_golden.py [--big]
 from __future__ import annotations
 
 import argparse
+import math
 import os
 import re
 import sys
@@ -532,6 +533,32 @@ def truecolor():
     log(f"  wrote {os.path.relpath(path, REPO)} ({os.path.getsize(path)} B)")
 
 
+def tiling_psnr(flca_mod):
+    """Config 4 in tiled mode: how far is the stitched frame of 8 independent tiles (2 x 4 grid, tile sizes multiples of 64
+    mosaic px, overlap 32 / 64 / 128) from the reference's untiled forward of the same frame?  (Tiles change the per-image
+    statistics -- luma maximum, attention norms and Gram, squeeze-excite pooling -- and cut the receptive field.)"""
+    import json
+    from bayer_low_light_image_enhancement_amd import tiling
+    m = fill(flca_mod.RawFormer(dim=64), 164)
+    x = t(synth.bayer_mosaic(10, 1, 2848, 4256))
+    with torch.no_grad():
+        whole = m(x)
+        res = {}
+        for ov in (32, 64, 128):
+            tiles = tiling.plan_tiles(2848, 4256, (2, 4), overlap=ov, align=64)
+            out = tiling.forward_tiled(m, x, tiles)
+            d = (out - whole).double()
+            mse = float((d ** 2).mean())
+            res[str(ov)] = {"psnr_db": 10 * math.log10(1.0 / mse), "max_abs": float(d.abs().max()), "mean_abs": float(d.abs().mean()),
+                            "tiles": [list(tl.src) for tl in tiles]}
+            log(f"  config 4 tiled 2x4, overlap {ov}: PSNR(tiled, untiled reference) {res[str(ov)]['psnr_db']:.2f} dB, max-abs {res[str(ov)]['max_abs']:.3e}")
+    path = os.path.join(GOLD, "tiling_psnr.json")
+    with open(path, "w") as f:
+        json.dump({"frame": [2848, 4256], "grid": [2, 4], "align": 64, "model": "RawFormer-L(FLCA) dim=64, synth weights seed 164, mosaic seed 10",
+                   "output_range": [float(whole.min()), float(whole.max())], "overlap": res}, f, indent=1)
+    log(f"  wrote {os.path.relpath(path, REPO)}")
+
+
 def state_dict_keys(flca_mod):
     """Key names and shapes of the reference's state_dict (what test.py:88-91 loads strictly)."""
     import json
@@ -552,6 +579,7 @@ def main():
     ap.add_argument("--only-harness", action="store_true", help="only the evaluation-harness fixture (test.py helpers)")
     ap.add_argument("--only-attenblock", action="store_true", help="only the Attenblock.LuminanceAwareMHSA (a16) and WFB extras (a17) fixtures")
     ap.add_argument("--only-cfg4", action="store_true", help="only BASELINE config 4 (RawFormer-L, one 2848x4256 mosaic)")
+    ap.add_argument("--only-tiling", action="store_true", help="only tests/golden/tiling_psnr.json (config 4, tiled vs untiled reference; minutes of CPU)")
     ap.add_argument("--only-truecolor", action="store_true", help="only the TrueColorRawFormer fixtures (f4)")
     ap.add_argument("--only-ffab", action="store_true", help="only the FEB / FFAB / rfft2 / WMB-wavelet-branch fixtures (f2)")
     args = ap.parse_args()
@@ -568,6 +596,12 @@ def main():
         import_reference()
         attenblock()
         wfb_extras()
+        with open(os.path.join(GOLD, "PINNING.txt"), "a") as f:
+            f.write("\n".join(LOG) + "\n")
+        return
+    if args.only_tiling:
+        torch.set_num_threads(8)
+        tiling_psnr(import_reference()[0])
         with open(os.path.join(GOLD, "PINNING.txt"), "a") as f:
             f.write("\n".join(LOG) + "\n")
         return
