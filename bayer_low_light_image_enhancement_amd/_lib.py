@@ -41,6 +41,11 @@ SIGNATURES = {
     "rf_workspace_bytes": (_i, [_vp, _i, _i, _i, _psz]),
     "rf_forward": (_i, [_vp, _vp, _vp, _vp, _sz, _i, _i, _i, _i, _vp]),
     "rf_forward_stage": (_i, [_vp, _i, _vp, _vp, _vp, _vp, _sz, _i, _i, _i, _vp]),
+    "rf_flat_param_floats": (_i, [_vp, _psz]),
+    "rf_flat_offset": (_i, [_vp, _i, _psz]),
+    "rf_train_workspace_bytes": (_i, [_vp, _i, _i, _i, _psz]),
+    "rf_train_step": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _i, _i, _i, _i, _f, _vp]),
+    "rf_adam_step": (_i, [_vp, _vp, _vp, _vp, _sz, _f, _f, _f, _f, _f, _i, _i, _f, _vp]),
     "rf_pixel_unshuffle2": (_i, [_vp, _vp, _i, _i, _i, _i, _vp]),
     "rf_pixel_shuffle2": (_i, [_vp, _vp, _i, _i, _i, _i, _vp]),
     "rf_dwt_haar": (_i, [_vp, _vp, _i, _i, _i, _i, _vp]),

@@ -21,7 +21,7 @@ LIB = os.path.join(CSRC, "librawformer_hip.so")
 DIAG_LIB = os.path.join(CSRC, "librawformer_hip_diag.so")
 DIAG_SOURCES = ["rf_block.hip", "rf_model.hip", "rf_gemm1x1.hip"]
 SOURCES = ["rf_api.hip", "rf_model.hip", "rf_pack.hip", "rf_pointwise.hip", "rf_gemm1x1.hip",
-           "rf_conv3x3.hip", "rf_attn.hip", "rf_flca.hip", "rf_fused.hip", "rf_block.hip", "rf_harness.hip", "rf_tokattn.hip", "rf_wfb.hip", "rf_upcat.hip", "rf_fft.hip", "rf_ffab.hip", "rf_truecolor.hip"]
+           "rf_conv3x3.hip", "rf_attn.hip", "rf_flca.hip", "rf_fused.hip", "rf_block.hip", "rf_harness.hip", "rf_tokattn.hip", "rf_wfb.hip", "rf_upcat.hip", "rf_fft.hip", "rf_ffab.hip", "rf_truecolor.hip", "rf_train.hip", "rf_trainstep.hip"]
 FLAGS = ["-O3", "-std=c++17", "-fPIC", "--offload-arch=gfx950", "-Wall", "-Wno-unused-function"]
 
 
@@ -41,7 +41,7 @@ def _stale(target: str, deps) -> bool:
 
 def build_library(force: bool = False, verbose: bool = False) -> str:
     hipcc = _hipcc()
-    headers = [os.path.join(CSRC, "rf_common.h"), os.path.join(HERE, "..", "include", "rawformer_hip.h")]
+    headers = [os.path.join(CSRC, "rf_common.h"), os.path.join(CSRC, "rf_handle.h"), os.path.join(HERE, "..", "include", "rawformer_hip.h")]
     objs, jobs = [], []
     for src in SOURCES:
         s = os.path.join(CSRC, src)

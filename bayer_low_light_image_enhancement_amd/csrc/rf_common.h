@@ -263,6 +263,25 @@ int launch_tc_spatial(const float* feat, float* xs, const float* guide, const fl
 int launch_tc_residual(const float* xs, const float* r, float* x2, float* partial, int B, int C, int h, int w, hipStream_t st);
 int launch_tc_color_head(float* x, const float* const* prm, int B, size_t P, hipStream_t st);
 
+// ---- training kernels (rf_train.hip)
+size_t gram2_partial_floats(int B, int Ca, int Cb, int h, int w, int ntap);
+int launch_gram2(const float* a, int64_t a_bstride, int Ca, const float* b, int64_t b_bstride, int Cb, float* out, int ld, float* partial,
+                 int B, int h, int w, int ntap, int sy, int sx, int per_image, size_t out_istride, int accumulate, hipStream_t st);
+int launch_reduce_rows(const float* partial, float* out, int nrows, size_t n, int accumulate, hipStream_t st);
+int chan_sum_nblk(int P);
+int launch_chan_sum(const float* x, int64_t bstride, float* out, float* partial, int B, int C, int P, int accumulate, hipStream_t st);
+size_t ln_bwd_partial_floats(int B, int C, int P);
+int launch_ln_bwd(const float* x, const float* dy, const float* gamma, float* dx, float* dgb, float* partial,
+                  int B, int C, int P, float eps, int accumulate_dx, int accumulate_w, hipStream_t st);
+size_t dw_wgrad_partial_floats(int B, int C, int P);
+int launch_dw_wgrad(const float* x, const float* dy, float* dw, float* db, float* partial, int B, int C, int h, int w, int accumulate, hipStream_t st);
+int launch_ewise(const float* a, const float* b, float* out, size_t n, int mode, float slope, hipStream_t st);
+int launch_flip3x3(const float* w, float* out, int Cout, int Cin, int dense, hipStream_t st);
+int loss_nblk();
+int launch_loss(const float* pred, const float* gt, float* grad, float* loss_out, float* partial, size_t n, int mode, float eps, hipStream_t st);
+int launch_adam(float* p, const float* g, float* m, float* v, size_t n, float lr, float b1, float b2, float eps, float wd, int decoupled,
+                int step, float gscale, hipStream_t st);
+
 // ---- FLCA (rf_flca.hip)
 size_t guidance_scratch_floats(int B, int H, int W);
 // packed-or-mosaic input -> base planes in scratch (y, cr, cb at HxW; LL, mag at H/2 x W/2)

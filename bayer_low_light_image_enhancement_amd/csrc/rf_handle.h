@@ -1,0 +1,45 @@
+// The RawFormer handle (internal): parameter registry, packed-weight plan.  Shared by the forward schedule (rf_model.hip) and
+// the training schedule (rf_trainstep.hip).
+#pragma once
+#include <string>
+#include <unordered_map>
+#include <vector>
+#include "rf_common.h"
+
+struct Param {
+    std::string name;
+    int64_t shape[4];
+    int ndim;
+    const float* ptr;
+    size_t numel() const {
+        size_t n = 1;
+        for (int i = 0; i < ndim; ++i) n *= (size_t)shape[i];
+        return n;
+    }
+};
+
+enum PackKind { PK_1x1, PK_3x3, PK_CONVT, PK_1x1_B3 };
+struct PackItem {
+    int param;       // index of the raw weight
+    PackKind kind;
+    size_t offset;   // floats into the packed buffer
+    size_t floats;
+};
+
+struct rf_handle {
+    rf_config cfg;
+    std::vector<Param> params;
+    std::unordered_map<std::string, int> index;
+    std::vector<PackItem> packs;
+    std::unordered_map<std::string, int> pack_index;   // weight name -> packs[]
+    std::unordered_map<std::string, int> pack3_index;  // weight name -> packs[] entry of its b3 form
+    size_t packed_floats = 0;
+    size_t upcat_offset[3] = {0, 0, 0};   // composed decoder-step weights (rf_upcat.hip), floats into the packed buffer
+    const float* packed = nullptr;   // caller memory, valid after rf_pack_params
+    std::vector<size_t> flat_offset;  // float offset of every parameter in the flat parameter / gradient buffers (training)
+    size_t flat_floats = 0;
+};
+
+
+inline const float* rf_param_ptr(const rf_handle* h, const std::string& name) { return h->params[h->index.at(name)].ptr; }
+inline int rf_param_index(const rf_handle* h, const std::string& name) { return h->index.at(name); }

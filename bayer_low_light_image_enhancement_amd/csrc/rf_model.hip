@@ -10,37 +10,7 @@
 
 using namespace rf;
 
-struct Param {
-    std::string name;
-    int64_t shape[4];
-    int ndim;
-    const float* ptr;
-    size_t numel() const {
-        size_t n = 1;
-        for (int i = 0; i < ndim; ++i) n *= (size_t)shape[i];
-        return n;
-    }
-};
-
-enum PackKind { PK_1x1, PK_3x3, PK_CONVT, PK_1x1_B3 };
-struct PackItem {
-    int param;       // index of the raw weight
-    PackKind kind;
-    size_t offset;   // floats into the packed buffer
-    size_t floats;
-};
-
-struct rf_handle {
-    rf_config cfg;
-    std::vector<Param> params;
-    std::unordered_map<std::string, int> index;
-    std::vector<PackItem> packs;
-    std::unordered_map<std::string, int> pack_index;   // weight name -> packs[]
-    std::unordered_map<std::string, int> pack3_index;  // weight name -> packs[] entry of its b3 form
-    size_t packed_floats = 0;
-    size_t upcat_offset[3] = {0, 0, 0};   // composed decoder-step weights (rf_upcat.hip), floats into the packed buffer
-    const float* packed = nullptr;   // caller memory, valid after rf_pack_params
-};
+#include "rf_handle.h"
 
 namespace {
 
@@ -394,6 +364,11 @@ int rf_create(const rf_config* cfg, rf_handle** out) {
         add_param(h, "color_correction.tone_curve.0.bias", {32});
         add_param(h, "color_correction.tone_curve.2.weight", {1, 32, 1, 1});
         add_param(h, "color_correction.tone_curve.2.bias", {1});
+    }
+    // flat layout for training: registry order, every tensor on a 16-byte boundary (a LayerNorm's weight and bias stay adjacent)
+    for (const Param& q : h->params) {
+        h->flat_offset.push_back(h->flat_floats);
+        h->flat_floats += align_up(q.numel(), 4);
     }
     *out = h;
     return RF_OK;

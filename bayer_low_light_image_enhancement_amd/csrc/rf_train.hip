@@ -1,0 +1,416 @@
+// Backward kernels of the training step (/root/reference train.py:127-147, RawFomer_WFB_FFAB/train.py:124).
+// The reference trains through torch.autograd; here every adjoint is a hand-written gfx950 kernel or one of the forward
+// kernels run on transposed / flipped weights:
+//
+//   conv 1x1 / 3x3 / ConvTranspose2d   dX: the forward kernels on W^T (3x3: taps flipped);  dW: gram2_kernel (below)
+//   depthwise 3x3                      dX: the forward kernel on flipped taps;              dW, db: dw_wgrad_kernel
+//   LayerNorm over channels            ln_bwd_kernel (dx per pixel; dgamma, dbeta through fixed-order partials)
+//   GELU, LeakyReLU, residual adds     element-wise kernels
+//   L1 / Charbonnier loss              loss_kernel (value through fixed-order partials, gradient in the same pass)
+//   Adam                               adam_kernel on the flat parameter / gradient / moment buffers
+//
+// gram2: G[i][j] = sum over images and pixels of A[i][p] * B[j][p + shift], the weight gradient of a convolution with A = dOut
+// and B = the layer input (zero padded), one shift per tap.  Like the attention Gram it is a contraction over pixels: the pixel
+// axis is the MFMA K dimension (v_mfma_f32_16x16x4_f32, f32 accumulate: reference numerics), every lane streams rows of 4
+// consecutive pixels.  Pixel slabs are reduced through per-slab partials summed in a fixed order: gradients are bitwise
+// reproducible run to run (no float atomics).
+#include "rf_common.h"
+
+namespace rf {
+
+namespace {
+
+__device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
+
+// ---------------------------------------------------------------------------------------------
+// gram2.  Workgroup = (slab of pixels of one image, tile ti of 16 A rows, group tj of TJ*16 B rows).  NTAP = 1: one shift
+// (sy, sx), TJ = 4 B tiles per workgroup; NTAP = 9: the nine taps of a 3x3 window at once, TJ = 1.
+// partial[((slab * NTAP + tap) * Ca + i) * Cb + j]
+// ---------------------------------------------------------------------------------------------
+struct Gram2Args {
+    const float* a; int64_t a_bstride; int Ca;     // dOut  [B][Ca][h][w]
+    const float* b; int64_t b_bstride; int Cb;     // input [B][Cb][h][w]
+    float* partial;
+    int B, h, w, sy, sx, slab_px, slabs_per_image;
+};
+
+template <int NTAP>
+__global__ void __launch_bounds__(256) gram2_kernel(Gram2Args g) {
+    constexpr int TJ = NTAP == 1 ? 4 : 1;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int r = lane & 15, kq = lane >> 4;
+    const int slab = blockIdx.x, ti = blockIdx.y, tjg = blockIdx.z;
+    const int img = slab / g.slabs_per_image, sl = slab - img * g.slabs_per_image;
+    const int h = g.h, w = g.w, P = h * w;
+    const int n_lo = sl * g.slab_px, n_hi = (n_lo + g.slab_px < P) ? n_lo + g.slab_px : P;
+    const int ia = (16 * ti + r < g.Ca) ? 16 * ti + r : g.Ca - 1;
+    const float* arow = g.a + (size_t)img * g.a_bstride + (size_t)ia * P;
+    const float* brow[TJ];
+#pragma unroll
+    for (int t = 0; t < TJ; ++t) {
+        const int jb = 16 * (tjg * TJ + t) + r;
+        brow[t] = g.b + (size_t)img * g.b_bstride + (size_t)(jb < g.Cb ? jb : g.Cb - 1) * P;
+    }
+    f32x4 acc[NTAP][TJ];
+#pragma unroll
+    for (int k = 0; k < NTAP; ++k)
+#pragma unroll
+        for (int t = 0; t < TJ; ++t) acc[k][t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    // the 4 pixels of a lane sit in one row (w % 4 == 0); neighbours along x come from the aligned groups left and right
+    auto shifted = [&](const float* row, int y, int x, int sy, int sx, float (&v)[4]) {
+        const int yy = y + sy;
+        if (yy < 0 || yy >= h) { v[0] = v[1] = v[2] = v[3] = 0.f; return; }
+        const float* p = row + (size_t)yy * w + x;
+        const float4 c = ld4(p);
+        if (sx == 0) { v[0] = c.x; v[1] = c.y; v[2] = c.z; v[3] = c.w; }
+        else if (sx < 0) { const float l = x > 0 ? p[-1] : 0.f; v[0] = l; v[1] = c.x; v[2] = c.y; v[3] = c.z; }
+        else { const float rr = x + 4 < w ? p[4] : 0.f; v[0] = c.y; v[1] = c.z; v[2] = c.w; v[3] = rr; }
+    };
+    // the loop is wave-uniform: an MFMA takes its operands from ALL 64 lanes whatever EXEC says, so lanes past the end of the
+    // slab stay in the loop and feed zeros (clamped address, masked value)
+    for (int n0 = n_lo + wave * 16; n0 < n_hi; n0 += 64) {
+        const int nn = n0 + 4 * kq;
+        const bool ok = nn < n_hi;
+        const int n = ok ? nn : n_lo;
+        const int y = n / w, x = n - y * w;
+        const float4 av = ld4(arow + n);
+        const float aa[4] = {ok ? av.x : 0.f, ok ? av.y : 0.f, ok ? av.z : 0.f, ok ? av.w : 0.f};
+#pragma unroll
+        for (int t = 0; t < TJ; ++t) {
+            if constexpr (NTAP == 1) {
+                float bv[4];
+                shifted(brow[t], y, x, g.sy, g.sx, bv);
+#pragma unroll
+                for (int m = 0; m < 4; ++m) acc[0][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(aa[m], bv[m], acc[0][t], 0, 0, 0);
+            } else {
+#pragma unroll
+                for (int k = 0; k < 9; ++k) {
+                    float bv[4];
+                    shifted(brow[t], y, x, k / 3 - 1, k % 3 - 1, bv);
+#pragma unroll
+                    for (int m = 0; m < 4; ++m) acc[k][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(aa[m], bv[m], acc[k][t], 0, 0, 0);
+                }
+            }
+        }
+    }
+    __shared__ float red[4][16][17];
+#pragma unroll
+    for (int k = 0; k < NTAP; ++k)
+#pragma unroll
+        for (int t = 0; t < TJ; ++t) {
+            __syncthreads();
+#pragma unroll
+            for (int q = 0; q < 4; ++q) red[wave][4 * kq + q][r] = acc[k][t][q];
+            __syncthreads();
+            const int i = threadIdx.x >> 4, j = threadIdx.x & 15;       // 256 threads = the 16 x 16 tile
+            const int gi = 16 * ti + i, gj = 16 * (tjg * TJ + t) + j;
+            if (gi < g.Ca && gj < g.Cb)
+                g.partial[(((size_t)slab * NTAP + k) * g.Ca + gi) * g.Cb + gj] = ((red[0][i][j] + red[1][i][j]) + red[2][i][j]) + red[3][i][j];
+        }
+}
+
+// out[e] (+)= sum over slabs of partial[slab][e], in slab order
+__global__ void __launch_bounds__(256) reduce_partials_kernel(const float* __restrict__ partial, float* __restrict__ out, int nslab, size_t n, int accumulate) {
+    for (size_t e = blockIdx.x * 256ull + threadIdx.x; e < n; e += (size_t)gridDim.x * 256) {
+        float s = 0.f;
+        for (int k = 0; k < nslab; ++k) s += partial[(size_t)k * n + e];
+        out[e] = accumulate ? out[e] + s : s;
+    }
+}
+
+// gram2 partials [group][slab_in_group][tap][Ca][Cb] -> out[group][(i * ld + j) * ntap + tap]   (weight layout [Cout][Cin][taps];
+// group = image when the result is wanted per image, else one group over all slabs)
+__global__ void __launch_bounds__(256) reduce_gram2_kernel(const float* __restrict__ partial, float* __restrict__ out, int nslab_per_group, int ntap,
+                                                           int Ca, int Cb, int ld, size_t out_gstride, int accumulate) {
+    const size_t n = (size_t)ntap * Ca * Cb;
+    const int grp = blockIdx.y;
+    const float* pg = partial + (size_t)grp * nslab_per_group * n;
+    for (size_t e = blockIdx.x * 256ull + threadIdx.x; e < n; e += (size_t)gridDim.x * 256) {
+        float s = 0.f;
+        for (int k = 0; k < nslab_per_group; ++k) s += pg[(size_t)k * n + e];
+        const int j = (int)(e % Cb), i = (int)((e / Cb) % Ca), tap = (int)(e / ((size_t)Ca * Cb));
+        float* o = out + (size_t)grp * out_gstride + ((size_t)i * ld + j) * ntap + tap;
+        *o = accumulate ? *o + s : s;
+    }
+}
+
+// depthwise partials [(img, blk)][C][10] -> dw[c][9] and db[c]
+__global__ void __launch_bounds__(256) reduce_dw_kernel(const float* __restrict__ partial, float* __restrict__ dw, float* __restrict__ db, int nslab, int C, int accumulate) {
+    for (int e = blockIdx.x * 256 + threadIdx.x; e < C * 10; e += gridDim.x * 256) {
+        float s = 0.f;
+        for (int k = 0; k < nslab; ++k) s += partial[(size_t)k * C * 10 + e];
+        const int c = e / 10, t = e % 10;
+        float* o = t < 9 ? dw + c * 9 + t : (db ? db + c : nullptr);
+        if (o) *o = accumulate ? *o + s : s;
+    }
+}
+
+// channel sums (bias gradients): partial[(img * nblk + blk) * C + c]
+__global__ void __launch_bounds__(256) chan_sum_kernel(const float* __restrict__ x, int64_t bstride, float* __restrict__ partial, int C, int P, int nblk) {
+    const int blk = blockIdx.x, c = blockIdx.y, img = blockIdx.z;
+    const float* row = x + (size_t)img * bstride + (size_t)c * P;
+    const int per = (P + nblk - 1) / nblk;
+    const int lo = blk * per, hi = (lo + per < P) ? lo + per : P;
+    float s = 0.f;
+    for (int p = lo + threadIdx.x; p < hi; p += 256) s += row[p];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+    __shared__ float wsum[4];
+    if ((threadIdx.x & 63) == 0) wsum[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) partial[((size_t)img * nblk + blk) * C + c] = (wsum[0] + wsum[1]) + (wsum[2] + wsum[3]);
+}
+
+// ---------------------------------------------------------------------------------------------
+// LayerNorm over channels, backward.  One thread per pixel (lanes along pixels: every channel row is a coalesced stream).
+// dx = rstd (g - mean_c(g) - xhat mean_c(g xhat)),  g = dy gamma;  dgamma[c] = sum_p dy xhat,  dbeta[c] = sum_p dy.
+// partial[((img * nblk + blk) * 2 + {0,1}) * C + c]
+// ---------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) ln_bwd_kernel(const float* __restrict__ x, const float* __restrict__ dy, const float* __restrict__ gamma,
+                                                     float* __restrict__ dx, float* __restrict__ partial, int C, int P, int nblk, float eps, int accumulate_dx) {
+    const int blk = blockIdx.x, img = blockIdx.y;
+    const int p = blk * 256 + threadIdx.x;
+    const bool live = p < P;
+    const size_t base = (size_t)img * C * P + (live ? p : 0);
+    float mu = 0.f;
+    for (int c = 0; c < C; ++c) mu += x[base + (size_t)c * P];
+    mu /= (float)C;
+    float var = 0.f;
+    for (int c = 0; c < C; ++c) { const float d = x[base + (size_t)c * P] - mu; var = fmaf(d, d, var); }
+    const float rstd = 1.0f / sqrtf(var / (float)C + eps);
+    float s1 = 0.f, s2 = 0.f;
+    for (int c = 0; c < C; ++c) {
+        const float g = dy[base + (size_t)c * P] * gamma[c];
+        s1 += g;
+        s2 = fmaf(g, (x[base + (size_t)c * P] - mu) * rstd, s2);
+    }
+    s1 /= (float)C; s2 /= (float)C;
+    __shared__ float red[2][4];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (int c = 0; c < C; ++c) {
+        const float xh = (x[base + (size_t)c * P] - mu) * rstd;
+        const float d = live ? dy[base + (size_t)c * P] : 0.f;
+        if (live) {
+            const float v = rstd * (d * gamma[c] - s1 - xh * s2);
+            dx[base + (size_t)c * P] = accumulate_dx ? dx[base + (size_t)c * P] + v : v;
+        }
+        float a = d * xh, b = d;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) { a += __shfl_xor(a, o); b += __shfl_xor(b, o); }
+        __syncthreads();
+        if (lane == 0) { red[0][wave] = a; red[1][wave] = b; }
+        __syncthreads();
+        if (threadIdx.x < 2)
+            partial[(((size_t)img * nblk + blk) * 2 + threadIdx.x) * C + c] =
+                (red[threadIdx.x][0] + red[threadIdx.x][1]) + (red[threadIdx.x][2] + red[threadIdx.x][3]);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// depthwise 3x3: weight and bias gradients.  partial[((img * nblk + blk) * C + c) * 10 + {9 taps, bias}]
+// ---------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) dw_wgrad_kernel(const float* __restrict__ x, const float* __restrict__ dy, float* __restrict__ partial,
+                                                       int C, int h, int w, int nblk) {
+    const int blk = blockIdx.x, c = blockIdx.y, img = blockIdx.z;
+    const int P = h * w;
+    const float* xr = x + ((size_t)img * C + c) * P;
+    const float* dr = dy + ((size_t)img * C + c) * P;
+    const int per = (P + nblk - 1) / nblk;
+    const int lo = blk * per, hi = (lo + per < P) ? lo + per : P;
+    float s[10];
+#pragma unroll
+    for (int k = 0; k < 10; ++k) s[k] = 0.f;
+    for (int p = lo + threadIdx.x; p < hi; p += 256) {
+        const int y = p / w, xx = p - y * w;
+        const float d = dr[p];
+#pragma unroll
+        for (int k = 0; k < 9; ++k) {
+            const int yy = y + k / 3 - 1, xc = xx + k % 3 - 1;
+            if (yy >= 0 && yy < h && xc >= 0 && xc < w) s[k] = fmaf(d, xr[(size_t)yy * w + xc], s[k]);
+        }
+        s[9] += d;
+    }
+    __shared__ float red[10][4];
+#pragma unroll
+    for (int k = 0; k < 10; ++k) {
+        float v = s[k];
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+        if ((threadIdx.x & 63) == 0) red[k][threadIdx.x >> 6] = v;
+    }
+    __syncthreads();
+    if (threadIdx.x < 10)
+        partial[(((size_t)img * nblk + blk) * C + c) * 10 + threadIdx.x] = (red[threadIdx.x][0] + red[threadIdx.x][1]) + (red[threadIdx.x][2] + red[threadIdx.x][3]);
+}
+
+// ---------------------------------------------------------------------------------------------
+// element-wise
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ float gelu_grad(float v) {      // d/dv [ v Phi(v) ] = Phi(v) + v phi(v)
+    const float cdf = 0.5f * (1.0f + erff(v * 0.70710678118654752440f));
+    return cdf + v * 0.39894228040143267794f * expf(-0.5f * v * v);
+}
+// mode 0: out = a + b;  1: out = dy * gelu'(x) (a = dy, b = x);  2: out = dy * (y > 0 ? 1 : slope) (a = dy, b = y);
+// 3: out = gelu(a) (exact erf);  4: out += a
+__global__ void __launch_bounds__(256) ewise_kernel(const float* __restrict__ a, const float* __restrict__ b, float* __restrict__ out, size_t n, int mode, float slope) {
+    for (size_t i = blockIdx.x * 256ull + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+        float v;
+        if (mode == 0) v = a[i] + b[i];
+        else if (mode == 1) v = a[i] * gelu_grad(b[i]);
+        else if (mode == 2) v = a[i] * (b[i] > 0.f ? 1.0f : slope);
+        else if (mode == 3) v = 0.5f * a[i] * (1.0f + erff(a[i] * 0.70710678118654752440f));
+        else v = out[i] + a[i];
+        out[i] = v;
+    }
+}
+
+// w'[c][8 - t] = w[c][t] (depthwise);  w'[ci][co][2-dy][2-dx] = w[co][ci][dy][dx] (dense 3x3)
+__global__ void __launch_bounds__(256) flip_kernel(const float* __restrict__ w, float* __restrict__ out, int Cout, int Cin, int dense) {
+    const size_t total = (size_t)Cout * (dense ? Cin : 1) * 9;
+    for (size_t i = blockIdx.x * 256ull + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+        const int t = (int)(i % 9);
+        if (!dense) { out[i - t + 8 - t] = w[i]; continue; }
+        const int ci = (int)((i / 9) % Cin), co = (int)(i / ((size_t)9 * Cin));
+        out[((size_t)ci * Cout + co) * 9 + 8 - t] = w[i];
+    }
+}
+
+// loss (mode 0: L1 = mean |d|; 1: Charbonnier = mean sqrt(d^2 + eps^2), train.py:16-25) and its gradient w.r.t. pred
+__global__ void __launch_bounds__(256) loss_kernel(const float* __restrict__ pred, const float* __restrict__ gt, float* __restrict__ grad,
+                                                   float* __restrict__ partial, size_t n, int mode, float eps, float inv_n) {
+    float s = 0.f;
+    for (size_t i = blockIdx.x * 256ull + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+        const float d = pred[i] - gt[i];
+        if (mode == 0) { s += fabsf(d); grad[i] = (d > 0.f ? inv_n : d < 0.f ? -inv_n : 0.f); }
+        else { const float r = sqrtf(fmaf(d, d, eps * eps)); s += r; grad[i] = d / r * inv_n; }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+    __shared__ float wsum[4];
+    if ((threadIdx.x & 63) == 0) wsum[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) partial[blockIdx.x] = ((wsum[0] + wsum[1]) + (wsum[2] + wsum[3])) * inv_n;
+}
+
+// torch.optim.Adam (train.py:113; weight_decay > 0 with decoupled = 1 gives AdamW), one launch over the flat buffers
+__global__ void __launch_bounds__(256) adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v, size_t n,
+                                                   float lr, float b1, float b2, float eps, float wd, int decoupled, float bc1, float bc2, float gscale) {
+    for (size_t i = blockIdx.x * 256ull + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+        float gi = g[i] * gscale, pi = p[i];
+        if (wd != 0.f) { if (decoupled) pi *= 1.0f - lr * wd; else gi = fmaf(wd, pi, gi); }
+        const float mi = fmaf(b1, m[i], (1.0f - b1) * gi);
+        const float vi = fmaf(b2, v[i], (1.0f - b2) * gi * gi);
+        m[i] = mi; v[i] = vi;
+        p[i] = pi - lr / bc1 * mi / (sqrtf(vi) / sqrtf(bc2) + eps);
+    }
+}
+
+int grid1d(size_t n, int cap = 4096) {
+    int g = (int)((n + 255) / 256);
+    if (g > cap) g = cap;
+    return g < 1 ? 1 : g;
+}
+
+}  // namespace
+
+// ---- launchers (shared with the training schedule, rf_trainstep.hip) --------------------------------------------
+// slabs: pixels per slab a multiple of 64, about 1024 workgroups in flight
+static void gram2_slabs(int B, int P, int tiles, int* slab_px, int* per_image) {
+    int per = 1;
+    while ((long)B * per * tiles < 1024 && P / (per + 1) >= 2048) ++per;
+    int px = (P + per - 1) / per;
+    px = (px + 63) / 64 * 64;
+    *slab_px = px;
+    *per_image = (P + px - 1) / px;
+}
+
+size_t gram2_partial_floats(int B, int Ca, int Cb, int h, int w, int ntap) {
+    int px, per;
+    gram2_slabs(B, h * w, cdiv(Ca, 16) * cdiv(Cb, ntap == 1 ? 64 : 16), &px, &per);
+    return (size_t)B * per * ntap * Ca * Cb;
+}
+
+// out[(i * ld + j) * ntap + tap] = weight layout [Ca][ld >= Cb][taps] (ntap = 9: the 3x3 window in (dy, dx) row-major order;
+// ntap = 1: the single shift (sy, sx)); per_image: out[b * out_istride + ...] without the sum over images; accumulate adds
+int launch_gram2(const float* a, int64_t a_bstride, int Ca, const float* b, int64_t b_bstride, int Cb, float* out, int ld, float* partial,
+                 int B, int h, int w, int ntap, int sy, int sx, int per_image, size_t out_istride, int accumulate, hipStream_t st) {
+    RF_CHECK_ARG(w % 4 == 0 && aligned16(a) && aligned16(b) && a_bstride % 4 == 0 && b_bstride % 4 == 0,
+                 "gram2: width %d must be a multiple of 4 and the operands 16-byte aligned", w);
+    RF_CHECK_ARG(ntap == 1 || ntap == 9, "gram2: ntap must be 1 or 9");
+    Gram2Args g{a, a_bstride, Ca, b, b_bstride, Cb, partial, B, h, w, sy, sx, 0, 0};
+    gram2_slabs(B, h * w, cdiv(Ca, 16) * cdiv(Cb, ntap == 1 ? 64 : 16), &g.slab_px, &g.slabs_per_image);
+    const int nslab = B * g.slabs_per_image;
+    ProfScope prof(st, ntap == 1 ? "gram2_kernel<1>" : "gram2_kernel<9>", 2.0 * ntap * Ca * Cb * (double)B * h * w, 4.0 * (double)B * h * w * (Ca + Cb));
+    if (ntap == 1) gram2_kernel<1><<<dim3((unsigned)nslab, (unsigned)cdiv(Ca, 16), (unsigned)cdiv(Cb, 64)), 256, 0, st>>>(g);
+    else gram2_kernel<9><<<dim3((unsigned)nslab, (unsigned)cdiv(Ca, 16), (unsigned)cdiv(Cb, 16)), 256, 0, st>>>(g);
+    const size_t n = (size_t)ntap * Ca * Cb;
+    reduce_gram2_kernel<<<dim3((unsigned)grid1d(n, 256), per_image ? (unsigned)B : 1u), 256, 0, st>>>(
+        partial, out, per_image ? g.slabs_per_image : nslab, ntap, Ca, Cb, ld, out_istride, accumulate);
+    return check_launch("gram2");
+}
+
+// out[e] (+)= sum over rows of partial[row][e]
+int launch_reduce_rows(const float* partial, float* out, int nrows, size_t n, int accumulate, hipStream_t st) {
+    reduce_partials_kernel<<<grid1d(n), 256, 0, st>>>(partial, out, nrows, n, accumulate);
+    return check_launch("reduce_rows");
+}
+
+int chan_sum_nblk(int P) { int n = P / 4096; return n < 1 ? 1 : n > 64 ? 64 : n; }
+
+int launch_chan_sum(const float* x, int64_t bstride, float* out, float* partial, int B, int C, int P, int accumulate, hipStream_t st) {
+    const int nblk = chan_sum_nblk(P);
+    chan_sum_kernel<<<dim3((unsigned)nblk, (unsigned)C, (unsigned)B), 256, 0, st>>>(x, bstride, partial, C, P, nblk);
+    reduce_partials_kernel<<<grid1d(C), 256, 0, st>>>(partial, out, B * nblk, (size_t)C, accumulate);
+    return check_launch("chan_sum");
+}
+
+// dgb = [dgamma (C) | dbeta (C)], contiguous (the two LayerNorm parameters are neighbours in the flat gradient buffer)
+int launch_ln_bwd(const float* x, const float* dy, const float* gamma, float* dx, float* dgb, float* partial,
+                  int B, int C, int P, float eps, int accumulate_dx, int accumulate_w, hipStream_t st) {
+    const int nblk = cdiv(P, 256);
+    ProfScope prof(st, "ln_bwd_kernel", 12.0 * B * C * P, 12.0 * B * C * P);
+    ln_bwd_kernel<<<dim3((unsigned)nblk, (unsigned)B), 256, 0, st>>>(x, dy, gamma, dx, partial, C, P, nblk, eps, accumulate_dx);
+    reduce_partials_kernel<<<grid1d(2 * C), 256, 0, st>>>(partial, dgb, B * nblk, (size_t)2 * C, accumulate_w);
+    return check_launch("ln_bwd");
+}
+size_t ln_bwd_partial_floats(int B, int C, int P) { return (size_t)B * cdiv(P, 256) * 2 * C; }
+
+int dw_wgrad_nblk(int P) { int n = P / 8192; return n < 1 ? 1 : n > 32 ? 32 : n; }
+size_t dw_wgrad_partial_floats(int B, int C, int P) { return (size_t)B * dw_wgrad_nblk(P) * C * 10; }
+
+// dw[c][9] tap gradients, db[c] bias gradient (db may be null)
+int launch_dw_wgrad(const float* x, const float* dy, float* dw, float* db, float* partial, int B, int C, int h, int w, int accumulate, hipStream_t st) {
+    const int nblk = dw_wgrad_nblk(h * w);
+    ProfScope prof(st, "dw_wgrad_kernel", 20.0 * B * C * h * w, 8.0 * B * C * h * w);
+    dw_wgrad_kernel<<<dim3((unsigned)nblk, (unsigned)C, (unsigned)B), 256, 0, st>>>(x, dy, partial, C, h, w, nblk);
+    reduce_dw_kernel<<<grid1d((size_t)C * 10), 256, 0, st>>>(partial, dw, db, B * nblk, C, accumulate);
+    return check_launch("dw_wgrad");
+}
+
+int launch_ewise(const float* a, const float* b, float* out, size_t n, int mode, float slope, hipStream_t st) {
+    ewise_kernel<<<grid1d(n), 256, 0, st>>>(a, b, out, n, mode, slope);
+    return check_launch("ewise");
+}
+
+int launch_flip3x3(const float* w, float* out, int Cout, int Cin, int dense, hipStream_t st) {
+    flip_kernel<<<grid1d((size_t)Cout * (dense ? Cin : 1) * 9), 256, 0, st>>>(w, out, Cout, Cin, dense);
+    return check_launch("flip3x3");
+}
+
+int loss_nblk() { return 1024; }
+int launch_loss(const float* pred, const float* gt, float* grad, float* loss_out, float* partial, size_t n, int mode, float eps, hipStream_t st) {
+    loss_kernel<<<loss_nblk(), 256, 0, st>>>(pred, gt, grad, partial, n, mode, eps, 1.0f / (float)n);
+    reduce_partials_kernel<<<1, 256, 0, st>>>(partial, loss_out, loss_nblk(), 1, 0);
+    return check_launch("loss");
+}
+
+int launch_adam(float* p, const float* g, float* m, float* v, size_t n, float lr, float b1, float b2, float eps, float wd, int decoupled,
+                int step, float gscale, hipStream_t st) {
+    const float bc1 = 1.0f - powf(b1, (float)step), bc2 = 1.0f - powf(b2, (float)step);
+    ProfScope prof(st, "adam_kernel", 12.0 * n, 28.0 * n);
+    adam_kernel<<<grid1d(n), 256, 0, st>>>(p, g, m, v, n, lr, b1, b2, eps, wd, decoupled, bc1, bc2, gscale);
+    return check_launch("adam");
+}
+
+}  // namespace rf

@@ -92,6 +92,22 @@ int rf_forward(rf_handle* h, const float* in, float* out, void* workspace, size_
 int rf_forward_stage(rf_handle* h, int stage, const float* in, const float* packed, float* out, void* workspace,
                      size_t workspace_bytes, int B, int H, int W, void* stream);
 
+/* ---- training step (reference train.py:127-147: forward, loss, backward; optimiser train.py:113) ----
+ * Parameters, gradients and the Adam moments live in FLAT float buffers: parameter i of the registry sits at float offset
+ * rf_flat_offset(i) (16-byte aligned), rf_flat_param_floats floats in all.  The host points rf_set_param at views of its flat
+ * parameter buffer, all-reduces the flat gradient buffer across ranks (RCCL) and calls rf_adam_step on the three buffers.
+ * rf_train_step: in [B,1,2H,2W] mosaic, gt [B,3,2H,2W]; writes grads (flat), *loss_out (device float), optionally the prediction.
+ * loss_mode 0: L1 (RawFomer_WFB_FFAB/train.py:124); 1: Charbonnier sqrt(d^2 + eps^2) (train.py:16-25).
+ * Adjoint schedule so far for variant PLAIN (conv branch); packed W must be a multiple of 32. */
+int rf_flat_param_floats(const rf_handle* h, size_t* floats);
+int rf_flat_offset(const rf_handle* h, int index, size_t* offset);
+int rf_train_workspace_bytes(const rf_handle* h, int B, int H, int W, size_t* bytes);
+int rf_train_step(rf_handle* h, const float* in, const float* gt, float* grads, float* loss_out, float* pred_out, void* workspace,
+                  size_t workspace_bytes, int B, int H, int W, int loss_mode, float loss_eps, void* stream);
+/* torch.optim.Adam / AdamW (decoupled != 0) on flat buffers; grads are multiplied by grad_scale first (1 / world size). */
+int rf_adam_step(float* params, const float* grads, float* m, float* v, size_t n, float lr, float beta1, float beta2, float eps,
+                 float weight_decay, int decoupled, int step, float grad_scale, void* stream);
+
 /* ---- operators (parity-test surface) -----------------------------------------------------------
  * Each entry runs the kernels the forward uses for that operator at that shape.  Where the forward
  * fuses ACROSS operators the fused kernel belongs to the wider entry point: rf_chan_attn (no LayerNorm

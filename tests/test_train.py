@@ -1,0 +1,114 @@
+"""f3: training step.  GPU: gradients of every parameter from the HIP adjoint schedule against torch.autograd run on the CPU
+oracle (same loss), then two Adam steps against torch.optim.Adam.  CPU: gradient bucketing + all-reduce over two gloo ranks.
+
+Tolerance: gradients are sums over 10^3..10^5 pixels of products of O(1) terms; both sides accumulate in float32 in different
+orders.  |g_hip - g_ref| <= 2e-4 * max|g_ref| + 1e-6 per tensor (observed ~1e-5 relative)."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+import cases
+from bayer_low_light_image_enhancement_amd import synth
+from oracle import rawformer_ref as R
+
+
+def _oracle_grads(sd, x, gt, cfg, loss):
+    p = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
+    pred = R.rawformer_forward(p, x, cfg)
+    d = pred - gt
+    val = d.abs().mean() if loss == "l1" else torch.sqrt(d * d + 1e-3 ** 2).mean()
+    val.backward()
+    return float(val), {k: v.grad for k, v in p.items()}, pred.detach()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("loss,lrelu", [("l1", True), ("charbonnier", False)])
+def test_gradients_match_autograd_on_the_oracle(device, loss, lrelu):
+    from bayer_low_light_image_enhancement_amd import RawFormer
+    from bayer_low_light_image_enhancement_amd.train import Trainer
+    dim, seed, b, hm, wm = 16, 91, 2, 32, 128
+    sd = cases.model_state(dim, seed, "plain")
+    m = RawFormer(dim=dim, variant="plain", branch_lrelu=lrelu)
+    m.load_state_dict(sd, strict=True)
+    m = m.to(device).train()
+    x = torch.from_numpy(synth.bayer_mosaic(seed, b, hm, wm))
+    gt = torch.from_numpy(synth.smooth_rgb(seed, b, hm, wm))
+    cfg = R.RawFormerConfig(dim=dim, variant="plain", branch_lrelu=lrelu)
+    ref_loss, ref_g, ref_pred = _oracle_grads(sd, x, gt, cfg, loss)
+    tr = Trainer(m, loss=loss)
+    loss_dev, pred = tr.forward_backward(x.to(device), gt.to(device), want_pred=True)
+    assert float((pred.cpu() - ref_pred).abs().max()) <= 5e-5
+    assert abs(float(loss_dev) - ref_loss) <= 1e-5
+    worst = ("", 0.0)
+    for k, g in ref_g.items():
+        got = tr.grad_of(k).cpu()
+        err = float((got - g).abs().max())
+        scale = float(g.abs().max())
+        if err / (2e-4 * scale + 1e-6) > worst[1]:
+            worst = (k, err / (2e-4 * scale + 1e-6))
+    assert worst[1] <= 1.0, worst
+
+
+@pytest.mark.gpu
+def test_two_adam_steps_match_torch_optim(device):
+    from bayer_low_light_image_enhancement_amd import RawFormer
+    from bayer_low_light_image_enhancement_amd.train import Trainer
+    dim, seed, b, hm, wm = 16, 92, 1, 32, 64
+    sd = cases.model_state(dim, seed, "plain")
+    m = RawFormer(dim=dim, variant="plain")
+    m.load_state_dict(sd, strict=True)
+    m = m.to(device).train()
+    cfg = R.RawFormerConfig(dim=dim, variant="plain")
+    p = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
+    opt = torch.optim.Adam(list(p.values()), lr=1e-3)
+    tr = Trainer(m, lr=1e-3)
+    for it in range(2):
+        x = torch.from_numpy(synth.bayer_mosaic(seed + it, b, hm, wm))
+        gt = torch.from_numpy(synth.smooth_rgb(seed + it, b, hm, wm))
+        opt.zero_grad()
+        (R.rawformer_forward(p, x, cfg) - gt).abs().mean().backward()
+        opt.step()
+        tr.step(x.to(device), gt.to(device))
+    cur = {k: v.detach().cpu() for k, v in m.state_dict().items()}
+    for k, v in p.items():
+        # Adam's first steps move every weight by ~lr whatever the gradient's size: compare the updates, sign flips of
+        # near-zero gradients aside (those elements may legitimately differ by 2 lr)
+        d = (cur[k] - v.detach()).abs()
+        assert float((d > 2.5e-3).float().mean()) == 0.0 and float(d.mean()) <= 2e-4, (k, float(d.max()), float(d.mean()))
+    # the forward now runs on the updated weights (packed copies refreshed)
+    with torch.no_grad():
+        xe = torch.from_numpy(synth.bayer_mosaic(seed + 9, 1, hm, wm))
+        m.eval()
+        assert float((m(xe.to(device)).cpu() - R.rawformer_forward({k: v.detach() for k, v in p.items()}, xe, cfg)).abs().max()) <= 2e-3
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def _ddp_worker(rank, world, port, out):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from bayer_low_light_image_enhancement_amd.train import allreduce_flat, bucket_bounds
+    g = torch.arange(10_000, dtype=torch.float32) * (rank + 1)
+    allreduce_flat(g, bucket_floats=3000)                 # 4 buckets, the last one short
+    assert bucket_bounds(10_000, 3000) == [(0, 3000), (3000, 6000), (6000, 9000), (9000, 10_000)]
+    if rank == 0:
+        torch.save(g, out)
+    dist.destroy_process_group()
+
+
+def test_bucketed_gradient_allreduce_two_gloo_ranks(tmp_path):
+    out = str(tmp_path / "g.pt")
+    mp.spawn(_ddp_worker, args=(2, _free_port(), out), nprocs=2, join=True)
+    g = torch.load(out, weights_only=True)
+    assert torch.equal(g, torch.arange(10_000, dtype=torch.float32) * 3)
