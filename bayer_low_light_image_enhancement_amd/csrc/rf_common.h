@@ -282,6 +282,11 @@ int launch_loss(const float* pred, const float* gt, float* grad, float* loss_out
 int launch_adam(float* p, const float* g, float* m, float* v, size_t n, float lr, float b1, float b2, float eps, float wd, int decoupled,
                 int step, float gscale, hipStream_t st);
 
+size_t flca_bwd_scratch_floats(int B, int C, int h, int w);
+int launch_flca_backward(const float* feat, const float* guide, const float* xs, const float* dz, int64_t dz_bstride, const float* ch,
+                         const float* pool_partial, int pool_nblk, const float* const* prm, float* const* grd, float* dfeat, int accumulate,
+                         float* scratch, int B, int C, int h, int w, hipStream_t st);
+
 // ---- FLCA (rf_flca.hip)
 size_t guidance_scratch_floats(int B, int H, int W);
 // packed-or-mosaic input -> base planes in scratch (y, cr, cb at HxW; LL, mag at H/2 x W/2)

@@ -414,3 +414,200 @@ int launch_adam(float* p, const float* g, float* m, float* v, size_t n, float lr
 }
 
 }  // namespace rf
+
+// =================================================================================================
+// FLCA branch, backward (FrequencyawareLumaChromaAttentionRAWFormer.py:103-162).  Forward:
+//   S = 1 + alpha sigmoid(conv(g_low; w_low)) + beta tanh(conv(g_high; w_high)) + gamma sigmoid(conv(g_cr, g_cb; w_chr))
+//   xs = feat S;   ch = sigmoid(W3 relu(W1 mean_p(xs) + b1) + b3) per image;   z = xs ch
+// Backward of z w.r.t. feat and the 10 parameter tensors (the guidance planes carry no gradient: they come from the input):
+//   dch[b][c] = sum_p dz xs           -> squeeze-excite MLP backward (tiny, per image) -> dm[b][c] (gradient of the pooled mean)
+//   dxs = dz ch + dm / P;   dfeat = dxs S;   dS = dxs feat;   dalpha = sum dS a_low, ...;   d(conv outputs) -> tap sums
+// =================================================================================================
+namespace rf {
+namespace {
+
+__device__ __forceinline__ float sigm(float x) { return 1.0f / (1.0f + expf(-x)); }
+
+// dch partial: partial[((b * nblk + blk) * C + c)] = sum over the block's pixels of dz * xs
+__global__ void __launch_bounds__(256) flca_dch_kernel(const float* __restrict__ dz, int64_t dz_bstride, const float* __restrict__ xs, float* __restrict__ partial,
+                                                       int C, int P, int nblk) {
+    const int blk = blockIdx.x, c = blockIdx.y, b = blockIdx.z;
+    const float* d = dz + (size_t)b * dz_bstride + (size_t)c * P;
+    const float* x = xs + ((size_t)b * C + c) * P;
+    const int per = (P + nblk - 1) / nblk, lo = blk * per, hi = (lo + per < P) ? lo + per : P;
+    float s = 0.f;
+    for (int p = lo + threadIdx.x; p < hi; p += 256) s = fmaf(d[p], x[p], s);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+    __shared__ float ws[4];
+    if ((threadIdx.x & 63) == 0) ws[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) partial[((size_t)b * nblk + blk) * C + c] = (ws[0] + ws[1]) + (ws[2] + ws[3]);
+}
+
+// squeeze-excite backward, ONE workgroup looping over the images in order (weight gradients accumulate deterministically).
+// in: pooled sums partial (forward: flca partial / P = mean), dch partials;  out: dm[b][c] / P, gradients of se.1.{w,b}, se.3.{w,b}
+__global__ void __launch_bounds__(256) flca_se_bwd_kernel(const float* __restrict__ pool_partial, int pool_nblk, const float* __restrict__ dch_partial, int dch_nblk,
+                                                          const float* __restrict__ w1, const float* __restrict__ b1, const float* __restrict__ w3, const float* __restrict__ b3,
+                                                          float* __restrict__ dmP, float* __restrict__ gw1, float* __restrict__ gb1, float* __restrict__ gw3, float* __restrict__ gb3,
+                                                          int B, int C, int hid, int P) {
+    __shared__ float mean[512], dch[512], ds3[512], hv[64], dh[64];
+    for (int b = 0; b < B; ++b) {
+        for (int c = threadIdx.x; c < C; c += 256) {
+            float s = 0.f, d = 0.f;
+            for (int k = 0; k < pool_nblk; ++k) s += pool_partial[((size_t)b * pool_nblk + k) * C + c];
+            for (int k = 0; k < dch_nblk; ++k) d += dch_partial[((size_t)b * dch_nblk + k) * C + c];
+            mean[c] = s / (float)P;
+            dch[c] = d;
+        }
+        __syncthreads();
+        for (int m = threadIdx.x; m < hid; m += 256) {
+            float s = b1[m];
+            for (int c = 0; c < C; ++c) s = fmaf(w1[m * C + c], mean[c], s);
+            hv[m] = fmaxf(s, 0.f);
+        }
+        __syncthreads();
+        for (int c = threadIdx.x; c < C; c += 256) {
+            float s = b3[c];
+            for (int m = 0; m < hid; ++m) s = fmaf(w3[c * hid + m], hv[m], s);
+            const float chv = sigm(s);
+            ds3[c] = dch[c] * chv * (1.0f - chv);
+        }
+        __syncthreads();
+        for (int m = threadIdx.x; m < hid; m += 256) {
+            float s = 0.f;
+            for (int c = 0; c < C; ++c) s = fmaf(w3[c * hid + m], ds3[c], s);
+            dh[m] = hv[m] > 0.f ? s : 0.f;
+        }
+        __syncthreads();
+        for (int e = threadIdx.x; e < C * hid; e += 256) gw3[e] += ds3[e / hid] * hv[e % hid];       // [C][hid]
+        for (int c = threadIdx.x; c < C; c += 256) gb3[c] += ds3[c];
+        for (int e = threadIdx.x; e < hid * C; e += 256) gw1[e] += dh[e / C] * mean[e % C];          // [hid][C]
+        for (int m = threadIdx.x; m < hid; m += 256) gb1[m] += dh[m];
+        for (int c = threadIdx.x; c < C; c += 256) {
+            float s = 0.f;
+            for (int m = 0; m < hid; ++m) s = fmaf(w1[m * C + c], dh[m], s);
+            dmP[(size_t)b * C + c] = s / (float)P;
+        }
+        __syncthreads();
+    }
+}
+
+// spatial part: one thread per pixel; partial[((b * nblk + blk) * C + c) * 39 + {9 low taps, 9 high taps, 18 chroma taps, dalpha, dbeta, dgamma}]
+struct FlcaBwdArgs {
+    const float* feat; const float* guide; const float* dz; int64_t dz_bstride; const float* ch; const float* dmP;
+    const float* w_low; const float* w_high; const float* w_chr; const float* alpha; const float* beta; const float* gamma;
+    float* dfeat; float* partial;
+    int C, h, w, nblk, accumulate;
+};
+
+__global__ void __launch_bounds__(256) flca_spatial_bwd_kernel(FlcaBwdArgs a) {
+    const int blk = blockIdx.x;
+    const size_t b = blockIdx.y;
+    const int h = a.h, w = a.w, P = h * w, C = a.C;
+    const int p = blk * 256 + threadIdx.x;
+    const bool live = p < P;
+    const int y = live ? p / w : 0, x = live ? p % w : 0;
+    float nb[4][9];
+    const float* gb = a.guide + b * 4 * (size_t)P;
+#pragma unroll
+    for (int pl = 0; pl < 4; ++pl)
+#pragma unroll
+        for (int t = 0; t < 9; ++t) {
+            const int yy = y + t / 3 - 1, xx = x + t % 3 - 1;
+            nb[pl][t] = (live && yy >= 0 && yy < h && xx >= 0 && xx < w) ? gb[(size_t)pl * P + (size_t)yy * w + xx] : 0.f;
+        }
+    const float al = *a.alpha, be = *a.beta, ga = *a.gamma;
+    __shared__ float red[39][4];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (int c = 0; c < C; ++c) {
+        const float* wl = a.w_low + c * 9;
+        const float* wh = a.w_high + c * 9;
+        const float* wc = a.w_chr + c * 18;
+        float sl = 0.f, sh = 0.f, sc = 0.f;
+#pragma unroll
+        for (int t = 0; t < 9; ++t) {
+            sl = fmaf(wl[t], nb[0][t], sl);
+            sh = fmaf(wh[t], nb[1][t], sh);
+            sc = fmaf(wc[9 + t], nb[3][t], fmaf(wc[t], nb[2][t], sc));
+        }
+        const float a_l = sigm(sl), a_h = tanhf(sh), a_c = sigm(sc);
+        float dS = 0.f;
+        if (live) {
+            const size_t idx = (b * C + c) * (size_t)P + p;
+            const float dxs = a.dz[b * a.dz_bstride + (size_t)c * P + p] * a.ch[b * C + c] + a.dmP[b * C + c];
+            const float S = 1.0f + al * a_l + be * a_h + ga * a_c;
+            const float df = dxs * S;
+            a.dfeat[idx] = a.accumulate ? a.dfeat[idx] + df : df;
+            dS = dxs * a.feat[idx];
+        }
+        float v[39];
+        const float dl = al * dS * a_l * (1.0f - a_l), dh = be * dS * (1.0f - a_h * a_h), dc = ga * dS * a_c * (1.0f - a_c);
+#pragma unroll
+        for (int t = 0; t < 9; ++t) { v[t] = dl * nb[0][t]; v[9 + t] = dh * nb[1][t]; v[18 + t] = dc * nb[2][t]; v[27 + t] = dc * nb[3][t]; }
+        v[36] = dS * a_l; v[37] = dS * a_h; v[38] = dS * a_c;
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < 39; ++k) {
+            float s = v[k];
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+            if (lane == 0) red[k][wave] = s;
+        }
+        __syncthreads();
+        if (threadIdx.x < 39)
+            a.partial[((b * a.nblk + blk) * C + c) * 39 + threadIdx.x] = (red[threadIdx.x][0] + red[threadIdx.x][1]) + (red[threadIdx.x][2] + red[threadIdx.x][3]);
+    }
+}
+
+// partial [(b, blk)][C][39] -> gradients of low_attn.0.weight [C][9], high_attn.0.weight [C][9], chroma_attn.0.weight [C][18], alpha, beta, gamma
+__global__ void __launch_bounds__(256) flca_reduce_kernel(const float* __restrict__ partial, int nrec, int C, float* __restrict__ g_low, float* __restrict__ g_high,
+                                                          float* __restrict__ g_chr, float* __restrict__ g_abg /* [3] scratch per channel: [C][3] */) {
+    for (int e = blockIdx.x * 256 + threadIdx.x; e < C * 39; e += gridDim.x * 256) {
+        float s = 0.f;
+        for (int k = 0; k < nrec; ++k) s += partial[(size_t)k * C * 39 + e];
+        const int c = e / 39, t = e % 39;
+        if (t < 9) g_low[c * 9 + t] += s;
+        else if (t < 18) g_high[c * 9 + t - 9] += s;
+        else if (t < 36) g_chr[c * 18 + t - 18] += s;
+        else g_abg[c * 3 + t - 36] = s;
+    }
+}
+
+__global__ void flca_abg_kernel(const float* __restrict__ g_abg, int C, float* __restrict__ ga, float* __restrict__ gb, float* __restrict__ gg) {
+    if (threadIdx.x < 3) {
+        float s = 0.f;
+        for (int c = 0; c < C; ++c) s += g_abg[c * 3 + threadIdx.x];
+        float* o = threadIdx.x == 0 ? ga : threadIdx.x == 1 ? gb : gg;
+        *o += s;
+    }
+}
+
+}  // namespace
+
+size_t flca_bwd_scratch_floats(int B, int C, int h, int w) {
+    const int P = h * w;
+    return (size_t)B * cdiv(P, 256) * C * 39 + (size_t)B * chan_sum_nblk(P) * C + 2 * (size_t)B * C + 3 * (size_t)C + 256;
+}
+
+// prm / grd: alpha, beta, gamma, low_attn.0.w, high_attn.0.w, chroma_attn.0.w, se.1.w, se.1.b, se.3.w, se.3.b (parameters / their gradients)
+int launch_flca_backward(const float* feat, const float* guide, const float* xs, const float* dz, int64_t dz_bstride, const float* ch,
+                         const float* pool_partial, int pool_nblk, const float* const* prm, float* const* grd, float* dfeat, int accumulate,
+                         float* scratch, int B, int C, int h, int w, hipStream_t st) {
+    RF_CHECK_ARG(C <= 512 && B <= 65535, "flca backward: C=%d > 512 not supported", C);
+    const int P = h * w, nblk = cdiv(P, 256), dnblk = chan_sum_nblk(P), hid = C / 8 > 8 ? C / 8 : 8;
+    float* part = scratch;
+    float* dch_part = part + (size_t)B * nblk * C * 39;
+    float* dmP = dch_part + (size_t)B * dnblk * C;
+    float* abg = dmP + (size_t)B * C;
+    ProfScope prof(st, "flca_backward(5 kernels)", 200.0 * B * C * P, 20.0 * B * C * P);
+    flca_dch_kernel<<<dim3((unsigned)dnblk, (unsigned)C, (unsigned)B), 256, 0, st>>>(dz, dz_bstride, xs, dch_part, C, P, dnblk);
+    flca_se_bwd_kernel<<<1, 256, 0, st>>>(pool_partial, pool_nblk, dch_part, dnblk, prm[6], prm[7], prm[8], prm[9], dmP, grd[6], grd[7], grd[8], grd[9], B, C, hid, P);
+    FlcaBwdArgs a{feat, guide, dz, dz_bstride, ch, dmP, prm[3], prm[4], prm[5], prm[0], prm[1], prm[2], dfeat, part, C, h, w, nblk, accumulate};
+    flca_spatial_bwd_kernel<<<dim3((unsigned)nblk, (unsigned)B), 256, 0, st>>>(a);
+    flca_reduce_kernel<<<grid1d((size_t)C * 39, 64), 256, 0, st>>>(part, B * nblk, C, grd[3], grd[4], grd[5], abg);
+    flca_abg_kernel<<<1, 64, 0, st>>>(abg, C, grd[0], grd[1], grd[2]);
+    return check_launch("flca_backward");
+}
+
+}  // namespace rf

@@ -17,7 +17,7 @@
 //       dS = A (dA - rowsum(dA A));  dT = sum dS c;  dc = T dS;
 //       dq = (rq dc rk) k - diag(rq^2 rowsum(dc c)) q;     dk = (rq dc rk)^T q - diag(rk^2 colsum(dc c)) k
 //     i.e. d[q;k] = M2 [q;k] with a per-image 2C x 2C matrix and dv = blockdiag(A^T) do: two 1x1 GEMMs with per-image weights.
-// Only variant 'plain' (conv branch) so far; the FLCA branch's adjoint is the next step.
+// Variants 'plain' (conv branch) and 'flca' (rf_train.hip: launch_flca_backward).
 #include <cstring>
 #include "rf_handle.h"
 
@@ -44,12 +44,14 @@ struct Bump {
 struct Stash {      // one Conv_Transformer stage
     const float* in;
     float *qkvp, *qkv, *partial, *x1, *f1, *f2, *trans, *xs, *cr, *out;
+    float *xraw, *ch, *pool;           // FLCA: xs before the squeeze-excite gate, the gate [B][C], the pooling partial sums
     int nslab, slab;
 };
 
 struct TrainPlan {
     Stash st[8];                       // 1..7
     float *x4, *e, *down[3], *up[3], *catr[3], *pred;
+    float *gscratch, *guide[4], *flca_scr;
     float *tA, *tB, *tC, *tD, *tE;     // backward temporaries (3 * U0 each)
     float *dskip[3], *dpred, *ga, *gb;
     float *wt1, *wt2;                  // on-the-fly packed / flipped weights
@@ -68,13 +70,22 @@ int make_train_plan(const rf_handle* h, float* base, int B, int H, int W, TrainP
     const int hcx = c.ffn_expansion;
     p.x4 = b.take((size_t)B * 4 * H * W);
     p.e = b.take(U0);
-    size_t part = 0, small = 0, wt = 0;
+    const bool flca = c.variant == RF_VARIANT_FLCA;
+    if (flca) {
+        p.gscratch = b.take(guidance_scratch_floats(B, H, W));
+        for (int l = 0; l < 4; ++l) p.guide[l] = b.take((size_t)B * 4 * (H >> l) * (W >> l));
+    }
+    size_t part = 0, small = 0, wt = 0, fscr = 0;
     auto stage = [&](int i, int lvl) -> int {
         const int C = c.dim << lvl, hh = H >> lvl, ww = W >> lvl;
         const size_t U = (size_t)B * C * hh * ww;
         Stash& s = p.st[i];
         s.qkvp = b.take(3 * U); s.qkv = b.take(3 * U); s.x1 = b.take(U); s.f1 = b.take(hcx * U); s.f2 = b.take(hcx * U);
         s.trans = b.take(U); s.xs = b.take(U); s.cr = b.take(U); s.out = b.take(U);
+        if (flca) {
+            s.xraw = b.take(U); s.ch = b.take((size_t)B * C); s.pool = b.take((size_t)B * flca_nblk(hh, ww) * C);
+            fscr = max_sz(fscr, flca_bwd_scratch_floats(B, C, hh, ww));
+        }
         size_t pf;
         RF_TRY(gram_plan(B, C, c.heads[lvl], hh * ww, &s.nslab, &s.slab, &pf));
         s.partial = b.take(pf);
@@ -109,6 +120,7 @@ int make_train_plan(const rf_handle* h, float* base, int B, int H, int W, TrainP
     p.part = b.take(max_sz(part, (size_t)B * 64 * 512));
     p.small = b.take(small);
     p.loss_part = b.take(4096);
+    p.flca_scr = b.take(fscr);
     p.total = b.off;
     return RF_OK;
 }
@@ -363,10 +375,24 @@ int stage_forward(const Ctx& c, int i, int lvl, const float* in, int H, int W) {
     RF_TRY(f_dw(c, s.f1, P(h, t + "ffn.depthwise.weight"), P(h, t + "ffn.depthwise.bias"), s.f2, hc, hh, ww));
     RF_TRY(launch_ewise(s.f2, nullptr, c.p->tA, (size_t)c.B * hc * Pn, 3, 0.f, c.st));                  // g = gelu(f2)
     RF_TRY(f_conv1x1(c, c.p->tA, hc, nullptr, 0, P(h, t + "ffn.pointwise2.weight"), P(h, t + "ffn.pointwise2.bias"), nullptr, nullptr, s.x1, s.trans, C, Pn));
-    RF_TRY(f_conv3x3(c, in, C, P(h, pre + "conv.weight"), P(h, pre + "conv.bias"), s.xs, C, hh, ww, cfg.branch_lrelu ? 1 : 0, 0));
+    if (cfg.variant == RF_VARIANT_FLCA) {
+        const std::string f = pre + "FLCA.";
+        FlcaSpatialArgs sa{};
+        sa.feat = in; sa.xs = s.xraw; sa.guide = c.p->guide[lvl];
+        sa.w_low = P(h, f + "low_attn.0.weight"); sa.w_high = P(h, f + "high_attn.0.weight"); sa.w_chr = P(h, f + "chroma_attn.0.weight");
+        sa.alpha = P(h, f + "alpha"); sa.beta = P(h, f + "beta"); sa.gamma = P(h, f + "gamma");
+        sa.partial = s.pool; sa.B = c.B; sa.C = C; sa.h = hh; sa.w = ww; sa.nblk = flca_nblk(hh, ww);
+        RF_TRY(launch_flca_spatial(sa, c.st));
+        const int hid = C / 8 > 8 ? C / 8 : 8;
+        RF_TRY(launch_flca_se(s.pool, sa.nblk, Pn, P(h, f + "se.1.weight"), P(h, f + "se.1.bias"), P(h, f + "se.3.weight"), P(h, f + "se.3.bias"),
+                              hid, s.ch, c.B, C, c.st));
+        RF_TRY(check_hip(hipMemcpyAsync(s.xs, s.xraw, U * 4, hipMemcpyDeviceToDevice, c.st), "copy"));
+        RF_TRY(launch_scale_channels(s.xs, s.ch, c.B, C, Pn, c.st));                                    // xs = branch output z
+    } else {
+        RF_TRY(f_conv3x3(c, in, C, P(h, pre + "conv.weight"), P(h, pre + "conv.bias"), s.xs, C, hh, ww, cfg.branch_lrelu ? 1 : 0, 0));
+    }
     RF_TRY(f_conv1x1(c, s.xs, C, s.trans, C, P(h, pre + "channel_reduce.weight"), P(h, pre + "channel_reduce.bias"), nullptr, nullptr, nullptr, s.cr, C, Pn));
     RF_TRY(f_conv3x3(c, s.cr, C, P(h, pre + "Conv_out.weight"), P(h, pre + "Conv_out.bias"), s.out, C, hh, ww, 1, 0));
-    (void)U;
     return RF_OK;
 }
 
@@ -392,10 +418,21 @@ int stage_backward(const Ctx& c, int i, int lvl, float* dout, float* din, int H,
         RF_TRY(check_hip(hipMemcpyAsync(tA + (size_t)b * C * Pn, tC + (size_t)b * 2 * C * Pn, (size_t)C * Pn * 4, hipMemcpyDeviceToDevice, c.st), "split"));
         RF_TRY(check_hip(hipMemcpyAsync(tD + (size_t)b * C * Pn, tC + ((size_t)b * 2 + 1) * C * Pn, (size_t)C * Pn * 4, hipMemcpyDeviceToDevice, c.st), "split"));
     }
-    // conv branch
-    if (cfg.branch_lrelu) RF_TRY(launch_ewise(tA, s.xs, tA, U, 2, 0.2f, c.st));
-    RF_TRY(b_conv3x3_dw(c, tA, C, s.in, C, c.G(pre + "conv.weight"), c.G(pre + "conv.bias"), hh, ww));
-    RF_TRY(b_conv3x3_dx(c, tA, C, P(h, pre + "conv.weight"), C, din, hh, ww));                        // din = branch part
+    if (cfg.variant == RF_VARIANT_FLCA) {
+        const std::string f = pre + "FLCA.";
+        const char* names[10] = {"alpha", "beta", "gamma", "low_attn.0.weight", "high_attn.0.weight", "chroma_attn.0.weight",
+                                 "se.1.weight", "se.1.bias", "se.3.weight", "se.3.bias"};
+        const float* prm[10];
+        float* grd[10];
+        for (int k = 0; k < 10; ++k) { prm[k] = P(h, f + names[k]); grd[k] = c.G(f + names[k]); }
+        RF_TRY(launch_flca_backward(s.in, c.p->guide[lvl], s.xraw, tA, (int64_t)C * Pn, s.ch, s.pool, flca_nblk(hh, ww), prm, grd, din, 0,
+                                    c.p->flca_scr, c.B, C, hh, ww, c.st));                             // din = branch part
+    } else {
+        // conv branch
+        if (cfg.branch_lrelu) RF_TRY(launch_ewise(tA, s.xs, tA, U, 2, 0.2f, c.st));
+        RF_TRY(b_conv3x3_dw(c, tA, C, s.in, C, c.G(pre + "conv.weight"), c.G(pre + "conv.bias"), hh, ww));
+        RF_TRY(b_conv3x3_dx(c, tA, C, P(h, pre + "conv.weight"), C, din, hh, ww));                    // din = branch part
+    }
     // FFN:  trans = x1 + pw2(gelu(dw(pw1(LN2(x1)))))          tD = dtrans (also the residual part of dx1)
     RF_TRY(launch_ewise(s.f2, nullptr, tA, (size_t)c.B * hc * Pn, 3, 0.f, c.st));                     // tA = g
     RF_TRY(b_conv1x1_dw(c, tD, C, tA, hc, c.G(t + "ffn.pointwise2.weight"), hc, 0, c.G(t + "ffn.pointwise2.bias"), hh, ww));
@@ -472,7 +509,8 @@ int rf_train_workspace_bytes(const rf_handle* h, int B, int H, int W, size_t* by
 int rf_train_step(rf_handle* h, const float* in, const float* gt, float* grads, float* loss_out, float* pred_out, void* workspace,
                   size_t workspace_bytes, int B, int H, int W, int loss_mode, float loss_eps, void* stream) {
     RF_CHECK_ARG(h && in && gt && grads && loss_out && workspace && aligned16(workspace) && aligned16(grads), "rf_train_step: bad arguments");
-    RF_CHECK_ARG(h->cfg.variant == RF_VARIANT_PLAIN && !h->cfg.clamp_io, "rf_train_step: only variant 'plain' without clamp_io has its adjoint so far");
+    RF_CHECK_ARG((h->cfg.variant == RF_VARIANT_PLAIN || h->cfg.variant == RF_VARIANT_FLCA) && !h->cfg.clamp_io,
+                 "rf_train_step: variants 'plain' and 'flca' without clamp_io have their adjoint so far");
     RF_CHECK_ARG(B > 0 && B <= 65535 && H % 8 == 0 && W % 8 == 0 && W % 32 == 0, "rf_train_step: packed size %dx%d (H %% 8, W %% 32 == 0)", H, W);
     for (const Param& q : h->params) RF_CHECK_ARG(q.ptr, "rf_train_step: parameter '%s' not set", q.name.c_str());
     TrainPlan p;
@@ -489,6 +527,10 @@ int rf_train_step(rf_handle* h, const float* in, const float* gt, float* grads, 
 
     // ------------------------------------------------------------------ forward
     RF_TRY(launch_pixel_unshuffle2(in, p.x4, B, 1, H, W, st));
+    if (cfg.variant == RF_VARIANT_FLCA) {
+        RF_TRY(launch_guidance_base(p.x4, 0, 0, p.gscratch, B, H, W, st));
+        for (int l = 0; l < 4; ++l) RF_TRY(launch_guidance_level(p.gscratch, p.guide[l], B, H, W, H >> l, W >> l, st));
+    }
     RF_TRY(f_conv3x3(c, p.x4, 4, P(h, "embedding.weight"), P(h, "embedding.bias"), p.e, d, H, W, 0, 0));
     const float* cur = p.e;
     for (int i = 1; i <= 3; ++i) {

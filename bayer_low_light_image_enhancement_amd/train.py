@@ -43,8 +43,8 @@ class Trainer:
 
     def __init__(self, model: RawFormer, lr: float = 1e-4, betas=(0.9, 0.999), eps: float = 1e-8, weight_decay: float = 0.0,
                  decoupled: bool = False, loss: str = "l1", charbonnier_eps: float = 1e-3, group=None):
-        if model.variant != "plain":
-            raise RuntimeError("Trainer: the adjoint schedule exists for variant='plain' so far (the FLCA branch is next)")
+        if model.variant not in ("plain", "flca"):
+            raise RuntimeError("Trainer: the adjoint schedule exists for variants 'plain' and 'flca'")
         dev = next(model.parameters()).device
         if dev.type != "cuda":
             raise RuntimeError("Trainer needs the model on a ROCm device: there is no CPU path in this package")

@@ -98,7 +98,7 @@ int rf_forward_stage(rf_handle* h, int stage, const float* in, const float* pack
  * parameter buffer, all-reduces the flat gradient buffer across ranks (RCCL) and calls rf_adam_step on the three buffers.
  * rf_train_step: in [B,1,2H,2W] mosaic, gt [B,3,2H,2W]; writes grads (flat), *loss_out (device float), optionally the prediction.
  * loss_mode 0: L1 (RawFomer_WFB_FFAB/train.py:124); 1: Charbonnier sqrt(d^2 + eps^2) (train.py:16-25).
- * Adjoint schedule so far for variant PLAIN (conv branch); packed W must be a multiple of 32. */
+ * Adjoint schedule for variants PLAIN and FLCA (no clamp_io); packed W must be a multiple of 32. */
 int rf_flat_param_floats(const rf_handle* h, size_t* floats);
 int rf_flat_offset(const rf_handle* h, int index, size_t* offset);
 int rf_train_workspace_bytes(const rf_handle* h, int B, int H, int W, size_t* bytes);
