@@ -163,16 +163,18 @@ __global__ void __launch_bounds__(256) chan_sum_kernel(const float* __restrict__
 }
 
 // ---------------------------------------------------------------------------------------------
-// LayerNorm over channels, backward.  One thread per pixel (lanes along pixels: every channel row is a coalesced stream).
-// dx = rstd (g - mean_c(g) - xhat mean_c(g xhat)),  g = dy gamma;  dgamma[c] = sum_p dy xhat,  dbeta[c] = sum_p dy.
-// partial[((img * nblk + blk) * 2 + {0,1}) * C + c]
+// LayerNorm over channels, backward.
+//   ln_bwd_kernel      one thread per pixel (lanes along pixels: every channel row is a coalesced stream):
+//                      dx = rstd (g - mean_c(g) - xhat mean_c(g xhat)),  g = dy gamma;  keeps mu and rstd of its pixel
+//   ln_wgrad_kernel    workgroup = (pixel block, channel, image): dgamma[c] = sum_p dy xhat, dbeta[c] = sum_p dy with ONE block
+//                      reduction per workgroup;  partial[((img * nblk + blk) * 2 + {0,1}) * C + c]
 // ---------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(256) ln_bwd_kernel(const float* __restrict__ x, const float* __restrict__ dy, const float* __restrict__ gamma,
-                                                     float* __restrict__ dx, float* __restrict__ partial, int C, int P, int nblk, float eps, int accumulate_dx) {
-    const int blk = blockIdx.x, img = blockIdx.y;
-    const int p = blk * 256 + threadIdx.x;
-    const bool live = p < P;
-    const size_t base = (size_t)img * C * P + (live ? p : 0);
+                                                     float* __restrict__ dx, float* __restrict__ stats, int C, int P, float eps, int accumulate_dx) {
+    const int img = blockIdx.y;
+    const int p = blockIdx.x * 256 + threadIdx.x;
+    if (p >= P) return;
+    const size_t base = (size_t)img * C * P + p;
     float mu = 0.f;
     for (int c = 0; c < C; ++c) mu += x[base + (size_t)c * P];
     mu /= (float)C;
@@ -186,25 +188,36 @@ __global__ void __launch_bounds__(256) ln_bwd_kernel(const float* __restrict__ x
         s2 = fmaf(g, (x[base + (size_t)c * P] - mu) * rstd, s2);
     }
     s1 /= (float)C; s2 /= (float)C;
-    __shared__ float red[2][4];
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     for (int c = 0; c < C; ++c) {
         const float xh = (x[base + (size_t)c * P] - mu) * rstd;
-        const float d = live ? dy[base + (size_t)c * P] : 0.f;
-        if (live) {
-            const float v = rstd * (d * gamma[c] - s1 - xh * s2);
-            dx[base + (size_t)c * P] = accumulate_dx ? dx[base + (size_t)c * P] + v : v;
-        }
-        float a = d * xh, b = d;
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) { a += __shfl_xor(a, o); b += __shfl_xor(b, o); }
-        __syncthreads();
-        if (lane == 0) { red[0][wave] = a; red[1][wave] = b; }
-        __syncthreads();
-        if (threadIdx.x < 2)
-            partial[(((size_t)img * nblk + blk) * 2 + threadIdx.x) * C + c] =
-                (red[threadIdx.x][0] + red[threadIdx.x][1]) + (red[threadIdx.x][2] + red[threadIdx.x][3]);
+        const float v = rstd * (dy[base + (size_t)c * P] * gamma[c] - s1 - xh * s2);
+        dx[base + (size_t)c * P] = accumulate_dx ? dx[base + (size_t)c * P] + v : v;
     }
+    stats[(size_t)img * 2 * P + p] = mu;
+    stats[(size_t)img * 2 * P + P + p] = rstd;
+}
+
+__global__ void __launch_bounds__(256) ln_wgrad_kernel(const float* __restrict__ x, const float* __restrict__ dy, const float* __restrict__ stats,
+                                                       float* __restrict__ partial, int C, int P, int nblk) {
+    const int blk = blockIdx.x, c = blockIdx.y, img = blockIdx.z;
+    const float* xr = x + ((size_t)img * C + c) * P;
+    const float* dr = dy + ((size_t)img * C + c) * P;
+    const float* mu = stats + (size_t)img * 2 * P;
+    const float* rs = mu + P;
+    const int per = ((P + nblk - 1) / nblk + 3) & ~3, lo = blk * per, hi = (lo + per < P) ? lo + per : P;
+    float a = 0.f, b = 0.f;
+    for (int p = lo + threadIdx.x; p < hi; p += 256) {
+        const float d = dr[p];
+        a = fmaf(d, (xr[p] - mu[p]) * rs[p], a);
+        b += d;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { a += __shfl_xor(a, o); b += __shfl_xor(b, o); }
+    __shared__ float red[2][4];
+    if ((threadIdx.x & 63) == 0) { red[0][threadIdx.x >> 6] = a; red[1][threadIdx.x >> 6] = b; }
+    __syncthreads();
+    if (threadIdx.x < 2)
+        partial[(((size_t)img * nblk + blk) * 2 + threadIdx.x) * C + c] = (red[threadIdx.x][0] + red[threadIdx.x][1]) + (red[threadIdx.x][2] + red[threadIdx.x][3]);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -365,16 +378,22 @@ int launch_chan_sum(const float* x, int64_t bstride, float* out, float* partial,
     return check_launch("chan_sum");
 }
 
-// dgb = [dgamma (C) | dbeta (C)], contiguous (the two LayerNorm parameters are neighbours in the flat gradient buffer)
+// dgb = [dgamma (C) | dbeta (C)], contiguous (the two LayerNorm parameters are neighbours in the flat gradient buffer);
+// partial: ln_bwd_partial_floats floats = per-pixel statistics + the per-block sums.  dx must not alias dy (the weight pass
+// reads dy after dx has been written).
+static int ln_nblk(int P) { int n = P / 4096; return n < 1 ? 1 : n > 64 ? 64 : n; }
 int launch_ln_bwd(const float* x, const float* dy, const float* gamma, float* dx, float* dgb, float* partial,
                   int B, int C, int P, float eps, int accumulate_dx, int accumulate_w, hipStream_t st) {
-    const int nblk = cdiv(P, 256);
-    ProfScope prof(st, "ln_bwd_kernel", 12.0 * B * C * P, 12.0 * B * C * P);
-    ln_bwd_kernel<<<dim3((unsigned)nblk, (unsigned)B), 256, 0, st>>>(x, dy, gamma, dx, partial, C, P, nblk, eps, accumulate_dx);
-    reduce_partials_kernel<<<grid1d(2 * C), 256, 0, st>>>(partial, dgb, B * nblk, (size_t)2 * C, accumulate_w);
+    const int nblk = ln_nblk(P);
+    float* stats = partial;
+    float* sums = partial + align_up((size_t)B * 2 * P, 64);
+    ProfScope prof(st, "ln_bwd(2 kernels)", 14.0 * B * C * P, 20.0 * B * C * P);
+    ln_bwd_kernel<<<dim3((unsigned)cdiv(P, 256), (unsigned)B), 256, 0, st>>>(x, dy, gamma, dx, stats, C, P, eps, accumulate_dx);
+    ln_wgrad_kernel<<<dim3((unsigned)nblk, (unsigned)C, (unsigned)B), 256, 0, st>>>(x, dy, stats, sums, C, P, nblk);
+    reduce_partials_kernel<<<grid1d(2 * C), 256, 0, st>>>(sums, dgb, B * nblk, (size_t)2 * C, accumulate_w);
     return check_launch("ln_bwd");
 }
-size_t ln_bwd_partial_floats(int B, int C, int P) { return (size_t)B * cdiv(P, 256) * 2 * C; }
+size_t ln_bwd_partial_floats(int B, int C, int P) { return align_up((size_t)B * 2 * P, 64) + (size_t)B * ln_nblk(P) * 2 * C; }
 
 int dw_wgrad_nblk(int P) { int n = P / 8192; return n < 1 ? 1 : n > 32 ? 32 : n; }
 size_t dw_wgrad_partial_floats(int B, int C, int P) { return (size_t)B * dw_wgrad_nblk(P) * C * 10; }
@@ -493,12 +512,16 @@ __global__ void __launch_bounds__(256) flca_se_bwd_kernel(const float* __restric
     }
 }
 
-// spatial part: one thread per pixel; partial[((b * nblk + blk) * C + c) * 39 + {9 low taps, 9 high taps, 18 chroma taps, dalpha, dbeta, dgamma}]
+// spatial part, element-wise: one thread per pixel, channels in a loop (the guidance neighbourhoods stay in registers).
+//   dfeat = dxs S;   ds_low = alpha dS a_l (1 - a_l),  ds_high = beta dS (1 - a_h^2),  ds_chr = gamma dS a_c (1 - a_c)   (dS = dxs feat)
+// are written out: the tap sums dW[c][tap] = sum_p ds[c][p] g[p + tap] are then weight gradients of a 3x3 convolution with a
+// 1- or 2-plane input = gram2<9>.  dalpha, dbeta, dgamma accumulate per thread over all channels: one block reduction at the end.
 struct FlcaBwdArgs {
     const float* feat; const float* guide; const float* dz; int64_t dz_bstride; const float* ch; const float* dmP;
     const float* w_low; const float* w_high; const float* w_chr; const float* alpha; const float* beta; const float* gamma;
-    float* dfeat; float* partial;
-    int C, h, w, nblk, accumulate;
+    float* dfeat; float* ds;        // ds: [3][B][C][P]
+    float* abg_partial;             // [(b * nblk + blk)][3]
+    int B, C, h, w, nblk, accumulate;
 };
 
 __global__ void __launch_bounds__(256) flca_spatial_bwd_kernel(FlcaBwdArgs a) {
@@ -518,66 +541,45 @@ __global__ void __launch_bounds__(256) flca_spatial_bwd_kernel(FlcaBwdArgs a) {
             nb[pl][t] = (live && yy >= 0 && yy < h && xx >= 0 && xx < w) ? gb[(size_t)pl * P + (size_t)yy * w + xx] : 0.f;
         }
     const float al = *a.alpha, be = *a.beta, ga = *a.gamma;
-    __shared__ float red[39][4];
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    for (int c = 0; c < C; ++c) {
-        const float* wl = a.w_low + c * 9;
-        const float* wh = a.w_high + c * 9;
-        const float* wc = a.w_chr + c * 18;
-        float sl = 0.f, sh = 0.f, sc = 0.f;
+    const size_t plane = (size_t)a.B * C * P;
+    float sa = 0.f, sb = 0.f, sg = 0.f;
+    if (live) {
+        for (int c = 0; c < C; ++c) {
+            const float* wl = a.w_low + c * 9;
+            const float* wh = a.w_high + c * 9;
+            const float* wc = a.w_chr + c * 18;
+            float sl = 0.f, sh = 0.f, sc = 0.f;
 #pragma unroll
-        for (int t = 0; t < 9; ++t) {
-            sl = fmaf(wl[t], nb[0][t], sl);
-            sh = fmaf(wh[t], nb[1][t], sh);
-            sc = fmaf(wc[9 + t], nb[3][t], fmaf(wc[t], nb[2][t], sc));
-        }
-        const float a_l = sigm(sl), a_h = tanhf(sh), a_c = sigm(sc);
-        float dS = 0.f;
-        if (live) {
+            for (int t = 0; t < 9; ++t) {
+                sl = fmaf(wl[t], nb[0][t], sl);
+                sh = fmaf(wh[t], nb[1][t], sh);
+                sc = fmaf(wc[9 + t], nb[3][t], fmaf(wc[t], nb[2][t], sc));
+            }
+            const float a_l = sigm(sl), a_h = tanhf(sh), a_c = sigm(sc);
             const size_t idx = (b * C + c) * (size_t)P + p;
             const float dxs = a.dz[b * a.dz_bstride + (size_t)c * P + p] * a.ch[b * C + c] + a.dmP[b * C + c];
-            const float S = 1.0f + al * a_l + be * a_h + ga * a_c;
-            const float df = dxs * S;
+            const float df = dxs * (1.0f + al * a_l + be * a_h + ga * a_c);
             a.dfeat[idx] = a.accumulate ? a.dfeat[idx] + df : df;
-            dS = dxs * a.feat[idx];
+            const float dS = dxs * a.feat[idx];
+            a.ds[idx] = al * dS * a_l * (1.0f - a_l);
+            a.ds[plane + idx] = be * dS * (1.0f - a_h * a_h);
+            a.ds[2 * plane + idx] = ga * dS * a_c * (1.0f - a_c);
+            sa = fmaf(dS, a_l, sa); sb = fmaf(dS, a_h, sb); sg = fmaf(dS, a_c, sg);
         }
-        float v[39];
-        const float dl = al * dS * a_l * (1.0f - a_l), dh = be * dS * (1.0f - a_h * a_h), dc = ga * dS * a_c * (1.0f - a_c);
-#pragma unroll
-        for (int t = 0; t < 9; ++t) { v[t] = dl * nb[0][t]; v[9 + t] = dh * nb[1][t]; v[18 + t] = dc * nb[2][t]; v[27 + t] = dc * nb[3][t]; }
-        v[36] = dS * a_l; v[37] = dS * a_h; v[38] = dS * a_c;
-        __syncthreads();
-#pragma unroll
-        for (int k = 0; k < 39; ++k) {
-            float s = v[k];
-#pragma unroll
-            for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
-            if (lane == 0) red[k][wave] = s;
-        }
-        __syncthreads();
-        if (threadIdx.x < 39)
-            a.partial[((b * a.nblk + blk) * C + c) * 39 + threadIdx.x] = (red[threadIdx.x][0] + red[threadIdx.x][1]) + (red[threadIdx.x][2] + red[threadIdx.x][3]);
     }
+    __shared__ float red[3][4];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { sa += __shfl_xor(sa, o); sb += __shfl_xor(sb, o); sg += __shfl_xor(sg, o); }
+    if ((threadIdx.x & 63) == 0) { red[0][threadIdx.x >> 6] = sa; red[1][threadIdx.x >> 6] = sb; red[2][threadIdx.x >> 6] = sg; }
+    __syncthreads();
+    if (threadIdx.x < 3)
+        a.abg_partial[(b * a.nblk + blk) * 3 + threadIdx.x] = (red[threadIdx.x][0] + red[threadIdx.x][1]) + (red[threadIdx.x][2] + red[threadIdx.x][3]);
 }
 
-// partial [(b, blk)][C][39] -> gradients of low_attn.0.weight [C][9], high_attn.0.weight [C][9], chroma_attn.0.weight [C][18], alpha, beta, gamma
-__global__ void __launch_bounds__(256) flca_reduce_kernel(const float* __restrict__ partial, int nrec, int C, float* __restrict__ g_low, float* __restrict__ g_high,
-                                                          float* __restrict__ g_chr, float* __restrict__ g_abg /* [3] scratch per channel: [C][3] */) {
-    for (int e = blockIdx.x * 256 + threadIdx.x; e < C * 39; e += gridDim.x * 256) {
-        float s = 0.f;
-        for (int k = 0; k < nrec; ++k) s += partial[(size_t)k * C * 39 + e];
-        const int c = e / 39, t = e % 39;
-        if (t < 9) g_low[c * 9 + t] += s;
-        else if (t < 18) g_high[c * 9 + t - 9] += s;
-        else if (t < 36) g_chr[c * 18 + t - 18] += s;
-        else g_abg[c * 3 + t - 36] = s;
-    }
-}
-
-__global__ void flca_abg_kernel(const float* __restrict__ g_abg, int C, float* __restrict__ ga, float* __restrict__ gb, float* __restrict__ gg) {
+__global__ void flca_abg_kernel(const float* __restrict__ partial, int nrec, float* __restrict__ ga, float* __restrict__ gb, float* __restrict__ gg) {
     if (threadIdx.x < 3) {
         float s = 0.f;
-        for (int c = 0; c < C; ++c) s += g_abg[c * 3 + threadIdx.x];
+        for (int k = 0; k < nrec; ++k) s += partial[(size_t)k * 3 + threadIdx.x];
         float* o = threadIdx.x == 0 ? ga : threadIdx.x == 1 ? gb : gg;
         *o += s;
     }
@@ -587,27 +589,35 @@ __global__ void flca_abg_kernel(const float* __restrict__ g_abg, int C, float* _
 
 size_t flca_bwd_scratch_floats(int B, int C, int h, int w) {
     const int P = h * w;
-    return (size_t)B * cdiv(P, 256) * C * 39 + (size_t)B * chan_sum_nblk(P) * C + 2 * (size_t)B * C + 3 * (size_t)C + 256;
+    return 3 * (size_t)B * C * P + (size_t)B * cdiv(P, 256) * 3 + (size_t)B * chan_sum_nblk(P) * C + 2 * (size_t)B * C + 256 +
+           gram2_partial_floats(B, C, 2, h, w, 9);
 }
 
 // prm / grd: alpha, beta, gamma, low_attn.0.w, high_attn.0.w, chroma_attn.0.w, se.1.w, se.1.b, se.3.w, se.3.b (parameters / their gradients)
 int launch_flca_backward(const float* feat, const float* guide, const float* xs, const float* dz, int64_t dz_bstride, const float* ch,
                          const float* pool_partial, int pool_nblk, const float* const* prm, float* const* grd, float* dfeat, int accumulate,
                          float* scratch, int B, int C, int h, int w, hipStream_t st) {
-    RF_CHECK_ARG(C <= 512 && B <= 65535, "flca backward: C=%d > 512 not supported", C);
+    RF_CHECK_ARG(C <= 512 && B <= 65535 && w % 4 == 0, "flca backward: C=%d, w=%d unsupported", C, w);
     const int P = h * w, nblk = cdiv(P, 256), dnblk = chan_sum_nblk(P), hid = C / 8 > 8 ? C / 8 : 8;
-    float* part = scratch;
-    float* dch_part = part + (size_t)B * nblk * C * 39;
+    const size_t plane = (size_t)B * C * P;
+    float* ds = scratch;
+    float* abg = ds + 3 * plane;
+    float* dch_part = abg + (size_t)B * nblk * 3;
     float* dmP = dch_part + (size_t)B * dnblk * C;
-    float* abg = dmP + (size_t)B * C;
-    ProfScope prof(st, "flca_backward(5 kernels)", 200.0 * B * C * P, 20.0 * B * C * P);
-    flca_dch_kernel<<<dim3((unsigned)dnblk, (unsigned)C, (unsigned)B), 256, 0, st>>>(dz, dz_bstride, xs, dch_part, C, P, dnblk);
-    flca_se_bwd_kernel<<<1, 256, 0, st>>>(pool_partial, pool_nblk, dch_part, dnblk, prm[6], prm[7], prm[8], prm[9], dmP, grd[6], grd[7], grd[8], grd[9], B, C, hid, P);
-    FlcaBwdArgs a{feat, guide, dz, dz_bstride, ch, dmP, prm[3], prm[4], prm[5], prm[0], prm[1], prm[2], dfeat, part, C, h, w, nblk, accumulate};
-    flca_spatial_bwd_kernel<<<dim3((unsigned)nblk, (unsigned)B), 256, 0, st>>>(a);
-    flca_reduce_kernel<<<grid1d((size_t)C * 39, 64), 256, 0, st>>>(part, B * nblk, C, grd[3], grd[4], grd[5], abg);
-    flca_abg_kernel<<<1, 64, 0, st>>>(abg, C, grd[0], grd[1], grd[2]);
-    return check_launch("flca_backward");
+    float* gpart = dmP + (size_t)B * C + 64;
+    {
+        ProfScope prof(st, "flca_backward(elementwise)", 200.0 * B * C * P, 32.0 * B * C * P);
+        flca_dch_kernel<<<dim3((unsigned)dnblk, (unsigned)C, (unsigned)B), 256, 0, st>>>(dz, dz_bstride, xs, dch_part, C, P, dnblk);
+        flca_se_bwd_kernel<<<1, 256, 0, st>>>(pool_partial, pool_nblk, dch_part, dnblk, prm[6], prm[7], prm[8], prm[9], dmP, grd[6], grd[7], grd[8], grd[9], B, C, hid, P);
+        FlcaBwdArgs a{feat, guide, dz, dz_bstride, ch, dmP, prm[3], prm[4], prm[5], prm[0], prm[1], prm[2], dfeat, ds, abg, B, C, h, w, nblk, accumulate};
+        flca_spatial_bwd_kernel<<<dim3((unsigned)nblk, (unsigned)B), 256, 0, st>>>(a);
+        flca_abg_kernel<<<1, 64, 0, st>>>(abg, B * nblk, grd[0], grd[1], grd[2]);
+        if (int rc = check_launch("flca_backward")) return rc;
+    }
+    // tap sums = 3x3 weight gradients with the guidance planes as (1- or 2-channel) inputs
+    if (int rc = launch_gram2(ds, (int64_t)C * P, C, guide, (int64_t)4 * P, 1, grd[3], 1, gpart, B, h, w, 9, 0, 0, 0, 0, 1, st)) return rc;
+    if (int rc = launch_gram2(ds + plane, (int64_t)C * P, C, guide + P, (int64_t)4 * P, 1, grd[4], 1, gpart, B, h, w, 9, 0, 0, 0, 0, 1, st)) return rc;
+    return launch_gram2(ds + 2 * plane, (int64_t)C * P, C, guide + 2 * (size_t)P, (int64_t)4 * P, 2, grd[5], 2, gpart, B, h, w, 9, 0, 0, 0, 0, 1, st);
 }
 
 }  // namespace rf

@@ -13,6 +13,9 @@ Multi-GPU (one process per GPU, RCCL):
   * cfg1/cfg2/cfg3/frame1: every rank runs the per-GPU batch on its own images -- the path shards along
     the batch with no data-path collective (weak scaling; only the timing barrier and the MAX over
     ranks use RCCL).
+  * cfg5 (BASELINE configs[4]): one TRAINING step per step -- forward, L1 loss, backward (explicit adjoint schedule,
+    rf_train_step), bucketed all-reduce of the flat 13.4 MB gradient buffer over RCCL INSIDE the timed region, AdamW on the flat
+    buffers; 4 images per GPU (weak scaling: 8 GPUs = the batch of 32 the config names).
   * cfg4 (RawFormer-L, one SID Sony frame 1x4x1424x2128): N = 1 runs the whole frame; N > 1 cuts it
     into N overlapping tiles (multiples of 64 mosaic px), rank r runs tile r and ONE all-gather of the
     tile outputs stitches the sRGB frame on every rank -- the collective is INSIDE the timed region
@@ -48,6 +51,7 @@ if REPO not in sys.path:
     sys.path.insert(0, REPO)
 
 PEAK_F32_MFMA_TFLOPS = 157.3   # MI355X_MICROARCH.md: v_mfma_f32_* = f32 vector rate
+PEAK_BF16_MFMA_TFLOPS = 2500.0 # dense bf16 MFMA (the bf16x3 GEMM kernels issue 6 bf16 products per f32 product)
 PEAK_HBM_GBS = 8000.0          # HBM3E spec
 
 WORKLOADS = {
@@ -57,6 +61,8 @@ WORKLOADS = {
     "cfg3": (48, 8, 1024, 1024, "RawFormer-B(FLCA) dim=48, batch=8 of packed 4x512x512 synthetic Bayer per GPU"),
     "cfg4": (64, 1, 2848, 4256, "RawFormer-L(FLCA) dim=64, one SID Sony full frame, packed 4x1424x2128"),
     "frame1": (32, 1, 1024, 1024, "RawFormer-S(FLCA) dim=32, ONE packed 4x512x512 frame (test.py:72 batch_size=1)"),
+    "cfg5": (32, 4, 1024, 1024, "RawFormer-S(FLCA) dim=32 TRAINING step (forward + L1 loss + backward + gradient all-reduce + AdamW), "
+                                "batch 4 of packed 4x512x512 per GPU"),
 }
 TILE_GRIDS = {1: (1, 1), 2: (1, 2), 3: (1, 3), 4: (2, 2), 5: (1, 5), 6: (2, 3), 7: (1, 7), 8: (2, 4)}
 TILE_OVERLAP = 64   # mosaic px of context per interior tile edge (tests/golden/tiling_psnr.json quantifies 32/64/128)
@@ -124,8 +130,15 @@ def profile_pass(fn, steps):
 
 def issued_over_algorithmic(kernel: str) -> float:
     """MFMA flops the kernel ISSUES per algorithmic flop.  The 3x3 convolutions use the Winograd F(4,3) form along x:
-    6 products per 4 outputs x 3 taps instead of 12."""
-    return 0.5 if kernel.startswith("conv3x3_kernel") else 1.0
+    6 products per 4 outputs x 3 taps instead of 12; the bf16x3 GEMM issues six bf16 products per
+    f32 product (three-piece split of both operands)."""
+    if kernel.startswith("conv3x3_kernel"):
+        return 0.5
+    return 6.0 if kernel.startswith("conv1x1_b3_kernel") else 1.0
+
+
+def pipe_peak(kernel: str) -> float:
+    return PEAK_BF16_MFMA_TFLOPS if kernel.startswith("conv1x1_b3_kernel") else PEAK_F32_MFMA_TFLOPS
 
 
 def roofline_of(rec):
@@ -138,11 +151,11 @@ def roofline_of(rec):
     if intensity >= PEAK_F32_MFMA_TFLOPS * 1e12 / (PEAK_HBM_GBS * 1e9):
         ratio = issued_over_algorithmic(rec["kernel"])
         ach = flops / (ms * 1e-3) / 1e12
-        peak = PEAK_F32_MFMA_TFLOPS / ratio
+        peak = pipe_peak(rec["kernel"]) / ratio
         return {"kernel": rec["kernel"], "bound": "mfma", "achieved": round(ach, 3), "peak": round(peak, 1),
                 "unit": "TFLOP/s", "frac": round(ach / peak, 4), "traffic": None,
                 "avg_launch_us": round(ms * 1e3, 2), "launches_per_step": None,
-                "mfma_peak_f32": PEAK_F32_MFMA_TFLOPS, "mfma_flops_issued_over_algorithmic": ratio,
+                "mfma_pipe_peak": pipe_peak(rec["kernel"]), "mfma_flops_issued_over_algorithmic": ratio,
                 "issued_tflops": round(ach * ratio, 3)}
     ach = byts / (ms * 1e-3) / 1e9
     return {"kernel": rec["kernel"], "bound": "hbm", "achieved": round(ach, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s",
@@ -351,7 +364,26 @@ def main():
         def forward(t):
             return model(t)
 
-    if tiled:
+    trainer = None
+    if args.workload == "cfg5":
+        seed0 = 2 + rank * batch
+        x = torch.from_numpy(synth.bayer_mosaic(seed0, batch, hm, wm)).to(device)
+        gt = torch.from_numpy(synth.smooth_rgb(seed0, batch, hm, wm)).to(device)
+        if args.dry_run:
+            from bayer_low_light_image_enhancement_amd.train import allreduce_flat
+            flat = torch.zeros(3_360_000)
+
+            def step():          # rehearses the bucketed gradient all-reduce only
+                allreduce_flat(flat)
+                return flat
+        else:
+            from bayer_low_light_image_enhancement_amd.train import Trainer
+            model.train()
+            trainer = Trainer(model, lr=1e-4, weight_decay=1e-2, decoupled=True, loss="l1")
+
+            def step():
+                return trainer.step(x, gt)
+    elif tiled:
         # strong scaling: ONE frame (same seed on every rank), N tiles, one per rank, one all-gather
         x = torch.from_numpy(synth.bayer_mosaic(10, 1, hm, wm)).to(device)
         tiles = tiling.plan_tiles(hm, wm, TILE_GRIDS[world], overlap=TILE_OVERLAP, align=TILE_ALIGN)
@@ -405,7 +437,8 @@ def main():
         "higher_is_better": True,
         "scaling": "strong" if args.workload == "cfg4" else "weak",
         "vs_baseline": None,
-        "dtype": "f32",
+        "dtype": "f32",     # storage, accumulation and results; the K >= 128 1x1 GEMMs contract three-piece bf16 splits of the f32
+                            # operands on the bf16 matrix pipe (same error as the f32 MFMA chain: profiles/r02_ubench_bf16x3.txt)
         "data": "synthetic",
         "config": {"workload": desc, "name": args.workload, "frames_per_gpu": batch, "mosaic": [hm, wm], "packed": [4, hm // 2, wm // 2],
                    "variant": "flca", "weights": "synthetic (seeded, random-init scale)",
@@ -417,8 +450,14 @@ def main():
         line["dry_run"] = True
         line["data"] = "synthetic; stand-in forward on CPU (launcher rehearsal, not a measurement)"
     log(f"timed region done: {elapsed / args.steps * 1e3:.3f} ms/step")
+    if args.workload == "cfg5":
+        line["metric"] = "megapixels/sec RawFormer-S 512x512 training step (AdamW + L1), data-parallel"
+        line["config"]["parallelism"] = f"data-parallel x{world}: flat-gradient all-reduce in 4 MiB buckets inside the timed region"
+        line["config"]["optimizer"] = "AdamW lr 1e-4 weight_decay 1e-2; L1 loss"
+        if trainer is not None:
+            line["config"]["final_loss"] = round(float(out), 6)
     if rank == 0 and not args.no_profile and not args.dry_run:
-        prof_step = (lambda: forward(x)) if not tiled else step
+        prof_step = step if (tiled or args.workload == "cfg5") else (lambda: forward(x))
         with torch.no_grad():
             recs = profile_pass(prof_step, args.steps)
         total = sum(r["ms"] for r in recs)

@@ -43,6 +43,14 @@ def test_cfg4_two_ranks_tile_sharded_with_the_all_gather_in_the_step():
     assert ", 2 tiles" in r.stderr
 
 
+def test_cfg5_two_ranks_rehearse_the_bucketed_gradient_all_reduce():
+    r = _run("--gpus", "2", "--dry-run", "--workload", "cfg5", "--steps", "2", "--warmup", "1")
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = _json_line(r.stdout)
+    assert line["n_gpus"] == 2 and line["scaling"] == "weak" and "training step" in line["metric"]
+    assert "all-reduce" in line["config"]["parallelism"]
+
+
 def test_world_size_mismatch_is_refused():
     r = _run("--gpus", "2", "--dry-run", env_extra={"WORLD_SIZE": "1", "RANK": "0", "LOCAL_RANK": "0"})
     assert r.returncode != 0 and "refusing" in (r.stderr + r.stdout)
