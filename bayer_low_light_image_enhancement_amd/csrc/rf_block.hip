@@ -54,7 +54,7 @@ int run_transformer(const TbParams& p, const float* in, float* out, float* ws, c
         // LN1 -> qkv 1x1 -> depthwise 3x3 -> {Gram partials, v} in one kernel: qkv never reaches HBM
         size_t pf;
         RF_TRY(fused_attn_plan(hh, ww, &nslab, &pf, B, C));
-        RF_TRY(launch_attn_front(in, bufB, partial, nslab, p.ln1_w, p.ln1_b, p.qkv_wp, p.qkv_b, p.qkv_dw_w, p.qkv_dw_b, B, C, hh, ww, st));
+        RF_TRY(launch_attn_front(in, bufB, partial, nslab, p.ln1_w, p.ln1_b, p.qkv_wp3, p.qkv_b, p.qkv_dw_w, p.qkv_dw_b, B, C, hh, ww, st));
         av.x1 = bufB; av.x1_bstride = (int64_t)C * Pn;
     } else {
         Conv1x1Args q{};

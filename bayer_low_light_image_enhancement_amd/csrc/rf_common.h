@@ -223,7 +223,7 @@ int launch_ffn_fused(const float* x, float* out, const float* ln_w, const float*
 bool fused_attn_supported(int C, int heads, int h, int w);
 int fused_attn_plan(int h, int w, int* nslab, size_t* partial_floats, int B, int C);
 int launch_attn_front(const float* x, float* v, float* partial, int nslab, const float* ln_w, const float* ln_b,
-                      const float* wp, const float* bq, const float* wd, const float* bd, int B, int C, int h, int w, hipStream_t st);
+                      const void* wp /* b3 */, const float* bq, const float* wd, const float* bd, int B, int C, int h, int w, hipStream_t st);
 
 // qkv [B,3C,h,w] -> depthwise 3x3 -> Gram partials of (q,k) + v, for C = 64 / 128
 bool attn_mid_supported(int C, int heads, int h, int w);

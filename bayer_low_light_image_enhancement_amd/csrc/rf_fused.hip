@@ -161,6 +161,102 @@ __device__ __forceinline__ void phase_a_step(const float4 (&xh)[C / 4], const fl
     }
 }
 
+// ---- b3 forms of the phase-A helpers (rf_common.h): lane (j, kq) holds channels 32 kb + 8 kq + i, i = 0..7 ------------------
+template <int C>
+__device__ __forceinline__ void load_step_b3(const float* __restrict__ xb, int P, int kq, const GroupGeom& g, float4 (&xh)[C / 4]) {
+    const unsigned voff = (unsigned)(8 * kq) * (unsigned)P + (unsigned)g.goff;
+#pragma unroll
+    for (int s = 0; s < C / 4; ++s) xh[s] = *reinterpret_cast<const float4*>(xb + (size_t)(32 * (s >> 3) + (s & 7)) * P + voff);
+}
+
+template <int C>
+__device__ __forceinline__ void ln_step_b3(int kq, const float* __restrict__ gam_l, const float* __restrict__ bet_l, float eps, float4 (&xh)[C / 4]) {
+    constexpr int NS = C / 4;
+    float sum[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int s = 0; s < NS; ++s) { sum[0] += xh[s].x; sum[1] += xh[s].y; sum[2] += xh[s].z; sum[3] += xh[s].w; }
+    float mu[4], var[4] = {0.f, 0.f, 0.f, 0.f}, rstd[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        sum[q] += __shfl_xor(sum[q], 16);
+        sum[q] += __shfl_xor(sum[q], 32);
+        mu[q] = sum[q] * (1.0f / C);
+    }
+#pragma unroll
+    for (int s = 0; s < NS; ++s) {
+        const float d0 = xh[s].x - mu[0], d1 = xh[s].y - mu[1], d2 = xh[s].z - mu[2], d3 = xh[s].w - mu[3];
+        var[0] = fmaf(d0, d0, var[0]); var[1] = fmaf(d1, d1, var[1]);
+        var[2] = fmaf(d2, d2, var[2]); var[3] = fmaf(d3, d3, var[3]);
+    }
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        var[q] += __shfl_xor(var[q], 16);
+        var[q] += __shfl_xor(var[q], 32);
+        rstd[q] = 1.0f / sqrtf(var[q] * (1.0f / C) + eps);
+    }
+#pragma unroll
+    for (int s = 0; s < NS; ++s) {
+        const int ch = 32 * (s >> 3) + 8 * kq + (s & 7);
+        const float gk = gam_l[ch], bk = bet_l[ch];
+        xh[s].x = fmaf((xh[s].x - mu[0]) * rstd[0], gk, bk);
+        xh[s].y = fmaf((xh[s].y - mu[1]) * rstd[1], gk, bk);
+        xh[s].z = fmaf((xh[s].z - mu[2]) * rstd[2], gk, bk);
+        xh[s].w = fmaf((xh[s].w - mu[3]) * rstd[3], gk, bk);
+    }
+}
+
+template <int C>
+__device__ __forceinline__ void split_step(const float4 (&xh)[C / 4], u32x4 (&bp)[C / 32][4][3]) {
+#pragma unroll
+    for (int kb = 0; kb < C / 32; ++kb)
+#pragma unroll
+        for (int hp = 0; hp < 4; ++hp) {
+            const float4 va = xh[8 * kb + 2 * hp], vb = xh[8 * kb + 2 * hp + 1];
+            const float xa[4] = {va.x, va.y, va.z, va.w}, xc[4] = {vb.x, vb.y, vb.z, vb.w};
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                unsigned a0, a1, a2, b0, b1, b2;
+                b3_split(xa[g], a0, a1, a2);
+                b3_split(xc[g], b0, b1, b2);
+                bp[kb][g][0][hp] = b3_pack(a0, b0);
+                bp[kb][g][1][hp] = b3_pack(a1, b1);
+                bp[kb][g][2][hp] = b3_pack(a2, b2);
+            }
+        }
+}
+
+template <int C, int WT>
+__device__ __forceinline__ void phase_a_step_b3(const u32x4 (&bp)[C / 32][4][3], const u32x4* __restrict__ wl,
+                                                int tile0, int tile1, const float* __restrict__ bias0, const float* __restrict__ bias1,
+                                                float* __restrict__ mid, int PS, int kq, const GroupGeom& g) {
+    f32x4 acc[2][4];
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) acc[t][q] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int kb = 0; kb < C / 32; ++kb) {
+        const u32x4* w0 = wl + (size_t)(kb * WT + tile0) * 192;
+        const u32x4* w1 = wl + (size_t)(kb * WT + tile1) * 192;
+        const u32x4 a0[3] = {w0[0], w0[64], w0[128]}, a1[3] = {w1[0], w1[64], w1[128]};
+#pragma unroll
+        for (int q = 0; q < 4; ++q) acc[0][q] = b3_mfma(a0, bp[kb][q], acc[0][q]);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) acc[1][q] = b3_mfma(a1, bp[kb][q], acc[1][q]);
+    }
+    if (g.lds_off >= 0) {
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float bs = (t ? bias1 : bias0)[4 * kq + r];
+                float4 v = make_float4(acc[t][0][r] + bs, acc[t][1][r] + bs, acc[t][2][r] + bs, acc[t][3][r] + bs);
+                if (!g.valid) v = make_float4(0.f, 0.f, 0.f, 0.f);
+                *reinterpret_cast<float4*>(mid + (16 * t + 4 * kq + r) * PS + g.lds_off) = v;
+            }
+    }
+}
+
 // 3x3 depthwise stencil for 4 consecutive pixels from an LDS plane: `p` points at the plane's
 // (row of the output pixel - 1, column of the first pixel), 16-byte aligned.  The two edge taps of
 // every row must not be scalar LDS reads (lanes 4 floats apart are a 4-way bank conflict on
@@ -372,7 +468,7 @@ struct AttnFrontArgs {
     float* v;              // [B][C][h][w]  depthwise-convolved v
     float* partial;        // [B][nslab][C/16][16][66]  (layout of rf_attn.hip: band of one k tile)
     const float* ln_w; const float* ln_b;
-    const float* wp;       // packed qkv weight [C/4][3C/16][64]
+    const void* wp;        // b3-packed qkv weight [C/32][3C/16][3][64] 16-byte elements
     const float* bq;       // [3C]
     const float* wd;       // [3C][9]
     const float* bd;       // [3C]
@@ -390,7 +486,7 @@ __global__ void __launch_bounds__(256, 2) attn_front_kernel(AttnFrontArgs a) {
     constexpr int PSV = 448;             // plane stride for the v parts: lanes run along pixels
     constexpr int ROWW = 4 * 16 + 2;     // partial row width of rf_attn.hip (kMaxBand * 16 + 2)
     __shared__ __attribute__((aligned(16))) float mid[PART * PSG + 8];
-    __shared__ __attribute__((aligned(16))) float w_l[NS * NT3 * 64];     // whole qkv weight, resident
+    __shared__ __attribute__((aligned(16))) u32x4 w_l[(C / 32) * NT3 * 192];     // whole qkv weight (b3), resident
     __shared__ float wd_l[3 * C * 9], bd_l[3 * C], bq_l[3 * C], gam_l[C], bet_l[C];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -400,7 +496,7 @@ __global__ void __launch_bounds__(256, 2) attn_front_kernel(AttnFrontArgs a) {
     const float* xb = a.x + (size_t)b * C * P;
     float* vb = a.v + (size_t)b * C * P;
 
-    for (int i = tid; i < NS * NT3 * 16; i += 256) *reinterpret_cast<float4*>(w_l + i * 4) = *reinterpret_cast<const float4*>(a.wp + i * 4);
+    for (int i = tid; i < (C / 32) * NT3 * 192; i += 256) w_l[i] = reinterpret_cast<const u32x4*>(a.wp)[i];
     for (int i = tid; i < 3 * C * 9; i += 256) wd_l[i] = a.wd[i];
     for (int i = tid; i < 3 * C; i += 256) { bd_l[i] = a.bd[i]; bq_l[i] = a.bq[i]; }
     for (int i = tid; i < C; i += 256) { gam_l[i] = a.ln_w[i]; bet_l[i] = a.ln_b[i]; }
@@ -410,22 +506,24 @@ __global__ void __launch_bounds__(256, 2) attn_front_kernel(AttnFrontArgs a) {
     for (int r = 0; r < NQT; ++r) { gq[r] = (f32x4){0.f, 0.f, 0.f, 0.f}; gnq[r] = gq[r]; gnk[r] = gq[r]; }
     STAMP_DECL
 
-    float4 xh0[NS], xh1[NS];
-    GroupGeom gn0, gn1;
-    if (slab < a.ntiles) {
-        gn0 = group_geom(wave, 0, j, (slab / a.tiles_x) * TH, (slab % a.tiles_x) * TW, h, w);
-        gn1 = group_geom(wave, 1, j, (slab / a.tiles_x) * TH, (slab % a.tiles_x) * TW, h, w);
-        load_step<C>(xb, P, kq, gn0, xh0);
-        load_step<C>(xb, P, kq, gn1, xh1);
-    }
+    float warm = 0.f;                                     // see the L2 warm-up below
     for (int tile = slab; tile < a.ntiles; tile += a.nslab) {
         const int tx = tile % a.tiles_x, ty = tile / a.tiles_x;
         const int x0 = tx * TW, y0 = ty * TH;
+        // The input tile is loaded here, not a tile ahead: the b3 pieces (96 registers) already fill the budget that the
+        // f32 kernel of round 1 spent on the next tile's raw values.  The loads are issued before the barrier so that their
+        // latency overlaps the wait, and the lines were pulled into L2 a tile ago (below).
+        const GroupGeom g0 = group_geom(wave, 0, j, y0, x0, h, w), g1 = group_geom(wave, 1, j, y0, x0, h, w);
+        float4 xh0[NS], xh1[NS];
+        load_step_b3<C>(xb, P, kq, g0, xh0);
+        load_step_b3<C>(xb, P, kq, g1, xh1);
         lds_barrier();                                   // weights visible; previous tile finished with mid
         STAMP(0);
-        const GroupGeom g0 = gn0, g1 = gn1;                // geometry of this tile (its loads were issued a tile ago)
-        ln_step<C>(kq, gam_l, bet_l, 1e-5f, xh0);
-        ln_step<C>(kq, gam_l, bet_l, 1e-5f, xh1);
+        ln_step_b3<C>(kq, gam_l, bet_l, 1e-5f, xh0);
+        ln_step_b3<C>(kq, gam_l, bet_l, 1e-5f, xh1);
+        u32x4 bp0[C / 32][4][3], bp1[C / 32][4][3];
+        split_step<C>(xh0, bp0);
+        split_step<C>(xh1, bp1);
         const int yo = y0 + wave;
         STAMP(1);
 
@@ -434,14 +532,14 @@ __global__ void __launch_bounds__(256, 2) attn_front_kernel(AttnFrontArgs a) {
         for (int r = 0; r < NQT; ++r) {
             if (r) lds_barrier();
             STAMP(0);
-            phase_a_step<C, NT3>(xh0, w_l + lane, r, NQT + r, bq_l + 16 * r, bq_l + C + 16 * r, mid, PSG, kq, g0);
-            phase_a_step<C, NT3>(xh1, w_l + lane, r, NQT + r, bq_l + 16 * r, bq_l + C + 16 * r, mid, PSG, kq, g1);
+            phase_a_step_b3<C, NT3>(bp0, w_l + lane, r, NQT + r, bq_l + 16 * r, bq_l + C + 16 * r, mid, PSG, kq, g0);
+            phase_a_step_b3<C, NT3>(bp1, w_l + lane, r, NQT + r, bq_l + 16 * r, bq_l + C + 16 * r, mid, PSG, kq, g1);
             STAMP(2);
             lds_barrier();
             STAMP(0);
             // phase B: lane (i = j, kq) owns channel i of the q tile and of the k tile at pixels x0 + 16*st + 4*kq + m
             const int cq = 16 * r + j, ck = C + 16 * r + j;
-#pragma unroll
+#pragma unroll 1                                         // unrolled, the hoisted stencil loads push the kernel into scratch
             for (int st = 0; st < 4; ++st) {
                 const int xo = x0 + 16 * st + 4 * kq;
                 const bool ok = yo < h && xo < w;
@@ -464,18 +562,25 @@ __global__ void __launch_bounds__(256, 2) attn_front_kernel(AttnFrontArgs a) {
             lds_barrier();
             STAMP(0);
             const int t0 = 2 * NQT + 2 * vp;
-            phase_a_step<C, NT3>(xh0, w_l + lane, t0, t0 + 1, bq_l + 2 * C + vp * PART, bq_l + 2 * C + vp * PART + 16, mid, PSV, kq, g0);
-            phase_a_step<C, NT3>(xh1, w_l + lane, t0, t0 + 1, bq_l + 2 * C + vp * PART, bq_l + 2 * C + vp * PART + 16, mid, PSV, kq, g1);
+            phase_a_step_b3<C, NT3>(bp0, w_l + lane, t0, t0 + 1, bq_l + 2 * C + vp * PART, bq_l + 2 * C + vp * PART + 16, mid, PSV, kq, g0);
+            phase_a_step_b3<C, NT3>(bp1, w_l + lane, t0, t0 + 1, bq_l + 2 * C + vp * PART, bq_l + 2 * C + vp * PART + 16, mid, PSV, kq, g1);
             STAMP(2);
-            if (vp == NVP - 1) {   // input registers are dead: fetch the next tile behind this phase B (before its stores)
+#ifndef RF_NO_WARM
+            if (vp == NVP - 1) {
+                // L2 warm-up for the next tile: its 6 rows x 32 channels x (72 px = at most 4 lines of 128 bytes) = 768 lines,
+                // three throw-away 4-byte loads per thread, consumed (added into `warm`) only after the next tile's own loads.
                 const int tn = tile + a.nslab;
                 if (tn < a.ntiles) {
-                    gn0 = group_geom(wave, 0, j, (tn / a.tiles_x) * TH, (tn % a.tiles_x) * TW, h, w);
-                    gn1 = group_geom(wave, 1, j, (tn / a.tiles_x) * TH, (tn % a.tiles_x) * TW, h, w);
-                    load_step<C>(xb, P, kq, gn0, xh0);
-                    load_step<C>(xb, P, kq, gn1, xh1);
+                    const int nx0 = (tn % a.tiles_x) * TW, ny0 = (tn / a.tiles_x) * TH;
+#pragma unroll
+                    for (int i = 0; i < 3; ++i) {
+                        const int idx = tid + 256 * i, ln = idx & 3, row = (idx >> 2) % HR, ch = idx / (4 * HR);
+                        const int yy = min(max(ny0 - 1 + row, 0), h - 1), xx = min(max(nx0 - 4 + 32 * ln, 0), w - 1);
+                        warm += xb[(size_t)ch * P + (size_t)yy * w + xx];
+                    }
                 }
             }
+#endif
             lds_barrier();
             STAMP(0);
             const int xo = x0 + 4 * j;
@@ -492,18 +597,20 @@ __global__ void __launch_bounds__(256, 2) attn_front_kernel(AttnFrontArgs a) {
         }
     }
     STAMP_FLUSH;
-    // ---- cross-wave reduction of the Gram tiles in a fixed order, one partial per workgroup
+    // ---- cross-wave reduction of the Gram tiles in a fixed order, one partial per workgroup.
+    // The zero key tiles of a partial row are written by their own strided loop, not next to the Gram values: hipcc 7.2 paired
+    // `rr[j] = g; rr[16 + j] = 0; rr[32 + j] = 0; rr[48 + j] = 0` into ds_write2_b32 with offset0 4 instead of 16 when the
+    // accumulators sat in AGPRs (seen with __launch_bounds__(256, 1)), i.e. zeros over the neighbouring Gram columns.
     __syncthreads();
     float* red = mid;                                      // [4 waves][16][ROWW] floats = 4224 <= PART * PSG
 #pragma unroll
     for (int r = 0; r < NQT; ++r) {
+        for (int i = tid; i < 64 * 48; i += 256) red[(i / 48) * ROWW + 16 + i % 48] = 0.f;
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             const int row = 4 * kq + q;
             float* rr = red + (wave * 16 + row) * ROWW;
             rr[j] = gq[r][q];
-#pragma unroll
-            for (int c = 16; c < 64; c += 16) rr[c + j] = 0.f;
             if (row == j) { rr[64] = gnq[r][q]; rr[65] = gnk[r][q]; }
         }
         __syncthreads();
@@ -512,6 +619,7 @@ __global__ void __launch_bounds__(256, 2) attn_front_kernel(AttnFrontArgs a) {
             dst[i] = ((red[i] + red[16 * ROWW + i]) + red[2 * 16 * ROWW + i]) + red[3 * 16 * ROWW + i];
         __syncthreads();
     }
+    if (a.B < 0) a.partial[0] = warm;                      // never true: keeps the warm-up loads alive
 }
 
 bool fused_attn_supported(int C, int heads, int h, int w) {
@@ -531,7 +639,7 @@ int fused_attn_plan(int h, int w, int* nslab, size_t* partial_floats, int B, int
 }
 
 int launch_attn_front(const float* x, float* v, float* partial, int nslab, const float* ln_w, const float* ln_b,
-                      const float* wp, const float* bq, const float* wd, const float* bd, int B, int C, int h, int w, hipStream_t st) {
+                      const void* wp, const float* bq, const float* wd, const float* bd, int B, int C, int h, int w, hipStream_t st) {
     RF_CHECK_ARG(C == 32 && w % 4 == 0 && B <= 65535, "attn_front: unsupported shape C=%d %dx%d", C, h, w);
     RF_CHECK_ARG(aligned16(x) && aligned16(v), "attn_front: buffers must be 16-byte aligned");
     AttnFrontArgs a{x, v, partial, ln_w, ln_b, wp, bq, wd, bd, B, h, w, cdiv(w, fused::TW), 0, nslab};

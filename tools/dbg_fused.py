@@ -11,7 +11,7 @@ from oracle import rawformer_ref as R
 dev = torch.device("cuda:0")
 c, heads = 32, 8
 p = params(cases.transformer_spec(c))
-for shp in ((2, c, 64, 64), (2, c, 256, 512), (8, c, 128, 256)):
+for shp in ((2, c, 64, 64), (8, c, 128, 256), (8, c, 512, 512)):
     x = rnd("tb.big.x", shp)
     torch.set_num_threads(16)
     ref = R.transformer_block(x, p, "", heads)
