@@ -120,6 +120,19 @@ __device__ __forceinline__ f32x4 b3_mfma(const u32x4 (&a)[3], const u32x4 (&b)[3
 #undef RF_B3
     return c;
 }
+// The same six terms for the four pixel sub-groups of a lane, term-major: an accumulator's six MFMAs form a dependent chain, and
+// a dependent v_mfma_f32_16x16x32_bf16 issued straight after its producer waits out the producer's 8 passes (measured: chains
+// issued one after the other run at half the 17-cycle issue rate).  Interleaved, three independent MFMAs sit between an
+// accumulator's consecutive terms.  Every accumulator still sees its terms in b3_mfma's order: the results are bit-identical.
+__device__ __forceinline__ void b3_mfma4(const u32x4 (&a)[3], const u32x4 (&b)[4][3], f32x4 (&c)[4]) {
+#define RF_B3(x) __builtin_bit_cast(bf16x8, x)
+#define RF_B3_TERM(ia, ib)                                                                                     \
+    _Pragma("unroll") for (int g = 0; g < 4; ++g)                                                              \
+        c[g] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(RF_B3(a[ia]), RF_B3(b[g][ib]), c[g], 0, 0, 0);
+    RF_B3_TERM(2, 0) RF_B3_TERM(0, 2) RF_B3_TERM(1, 1) RF_B3_TERM(1, 0) RF_B3_TERM(0, 1) RF_B3_TERM(0, 0)
+#undef RF_B3_TERM
+#undef RF_B3
+}
 #endif
 
 // ---- weight repacking (rf_pack.hip)

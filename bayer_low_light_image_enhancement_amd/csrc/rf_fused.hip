@@ -239,10 +239,8 @@ __device__ __forceinline__ void phase_a_step_b3(const u32x4 (&bp)[C / 32][4][3],
         const u32x4* w0 = wl + (size_t)(kb * WT + tile0) * 192;
         const u32x4* w1 = wl + (size_t)(kb * WT + tile1) * 192;
         const u32x4 a0[3] = {w0[0], w0[64], w0[128]}, a1[3] = {w1[0], w1[64], w1[128]};
-#pragma unroll
-        for (int q = 0; q < 4; ++q) acc[0][q] = b3_mfma(a0, bp[kb][q], acc[0][q]);
-#pragma unroll
-        for (int q = 0; q < 4; ++q) acc[1][q] = b3_mfma(a1, bp[kb][q], acc[1][q]);
+        b3_mfma4(a0, bp[kb], acc[0]);
+        b3_mfma4(a1, bp[kb], acc[1]);
     }
     if (g.lds_off >= 0) {
 #pragma unroll

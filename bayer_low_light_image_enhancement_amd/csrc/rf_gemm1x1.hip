@@ -595,13 +595,173 @@ __global__ void __launch_bounds__(256, 2) conv1x1_b3_kernel(Conv1x1Args a, int n
 #pragma unroll
         for (int t = 0; t < NCO; ++t) {
             const u32x4 ap[3] = {wl[(t * 3 + 0) * 64], wl[(t * 3 + 1) * 64], wl[(t * 3 + 2) * 64]};
-#pragma unroll
-            for (int g = 0; g < 4; ++g) acc[t][g] = b3_mfma(ap, bp[g], acc[t][g]);
+            b3_mfma4(ap, bp, acc[t]);
         }
         if (c + 1 < NB) store_w_block((c + 1) & 1);
         __syncthreads();
     }
     epilogue<NCO, false>(a, acc, t0, tcnt, bias_l, nullptr, b, p0, kq, live);
+}
+
+// ---------------------------------------------------------------------------------------------
+// LayerNorm + 1x1 at levels 2-3 (K = 128 / 256, Cout = 2K or 3K): the input tile is normalised and split ONCE.
+//   conv1x1_b3_kernel gives every workgroup 4-6 output tiles and re-reads, re-normalises and re-splits its 256 pixels for
+//   each of the Cout / 64 output groups (6 passes over x for the level-2 qkv).  Here a workgroup owns 64 pixels and ALL
+//   output tiles: the four waves load K / 4 channels each, reduce the two-pass statistics through LDS, write the three
+//   bf16 pieces of the normalised tile to LDS in B-operand order ([K block][pixel q][piece][lane], 12 KB per 32 channels),
+//   and then split the OUTPUT tiles: wave w computes tiles [w tpw, (w + 1) tpw) in chunks of NCO, reading the shared B
+//   pieces from LDS (once per chunk) and its A pieces straight from L2 (each weight element is used by exactly one wave of
+//   the workgroup), double-buffered one K block ahead.
+// ---------------------------------------------------------------------------------------------
+template <int KB, int NCO>
+__global__ void __launch_bounds__(256, KB <= 4 ? 2 : 1) conv1x1_b3_ln_kernel(Conv1x1Args a, int tpw) {
+    __shared__ __attribute__((aligned(16))) u32x4 Bl[KB * 768];
+    __shared__ __attribute__((aligned(16))) float red[2 * 4 * 64];
+    __shared__ float bias_l[1024];
+    constexpr int KPW = KB / 4;               // K blocks each wave loads
+    constexpr int K = 32 * KB;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int j = lane & 15, kq = lane >> 4;
+    const int b = blockIdx.y, P = a.P;
+    const int NT = a.Cout >> 4;
+    const int ntile = (P + 63) >> 6;
+    const float* xb = a.x1 + (size_t)b * a.x1_bstride;
+    const u32x4* wp3 = reinterpret_cast<const u32x4*>(reinterpret_cast<const float*>(a.wp3) + (size_t)b * a.wp3_bstride) + lane;
+    for (int i = tid; i < a.Cout; i += 256) bias_l[i] = a.bias ? a.bias[i] : 0.f;
+
+    // ---- input tile: wave w holds K blocks [w KPW, (w + 1) KPW), lane (j, kq) channels 8 kq .. 8 kq + 7 of each, 4 pixels.
+    // Persistent over pixel tiles: the next tile's loads are issued as soon as this one is split, i.e. behind its whole GEMM
+    // (without that the kernel ran at HBM time + MFMA time: all workgroups load, then all multiply).
+    float4 xr[KPW][8];
+    auto load_x = [&](int tile) {
+        const int q0 = tile * 64 + 4 * j;
+        const unsigned ql = (unsigned)(q0 < P ? q0 : 0);
+#pragma unroll
+        for (int i = 0; i < KPW; ++i)
+#pragma unroll
+            for (int c = 0; c < 8; ++c) xr[i][c] = ldv(xb, (unsigned)(32 * (wave * KPW + i) + 8 * kq + c) * (unsigned)P + ql);
+    };
+    constexpr bool PREF = KB > 4;          // K = 128 runs two workgroups per CU: no registers left for a tile in flight
+    if (PREF) load_x(blockIdx.x);
+    for (int tile = blockIdx.x; tile < ntile; tile += gridDim.x) {
+    if (!PREF) load_x(tile);
+    const int p0 = tile * 64 + 4 * j;
+    const bool live = p0 < P;
+    // two-pass statistics: lanes, then waves (fixed order)
+    float mean[4], rstd[4];
+    {
+        float s[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int i = 0; i < KPW; ++i)
+#pragma unroll
+            for (int c = 0; c < 8; ++c) { s[0] += xr[i][c].x; s[1] += xr[i][c].y; s[2] += xr[i][c].z; s[3] += xr[i][c].w; }
+#pragma unroll
+        for (int g = 0; g < 4; ++g) { s[g] += __shfl_xor(s[g], 16); s[g] += __shfl_xor(s[g], 32); }
+        if (kq == 0) *reinterpret_cast<float4*>(red + wave * 64 + 4 * j) = make_float4(s[0], s[1], s[2], s[3]);
+        __syncthreads();
+        const float4 r0 = *reinterpret_cast<const float4*>(red + 4 * j), r1 = *reinterpret_cast<const float4*>(red + 64 + 4 * j);
+        const float4 r2 = *reinterpret_cast<const float4*>(red + 128 + 4 * j), r3 = *reinterpret_cast<const float4*>(red + 192 + 4 * j);
+        mean[0] = (((r0.x + r1.x) + r2.x) + r3.x) * (1.0f / K); mean[1] = (((r0.y + r1.y) + r2.y) + r3.y) * (1.0f / K);
+        mean[2] = (((r0.z + r1.z) + r2.z) + r3.z) * (1.0f / K); mean[3] = (((r0.w + r1.w) + r2.w) + r3.w) * (1.0f / K);
+        float v[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int i = 0; i < KPW; ++i)
+#pragma unroll
+            for (int c = 0; c < 8; ++c) {
+                const float d0 = xr[i][c].x - mean[0], d1 = xr[i][c].y - mean[1], d2 = xr[i][c].z - mean[2], d3 = xr[i][c].w - mean[3];
+                v[0] = fmaf(d0, d0, v[0]); v[1] = fmaf(d1, d1, v[1]); v[2] = fmaf(d2, d2, v[2]); v[3] = fmaf(d3, d3, v[3]);
+            }
+#pragma unroll
+        for (int g = 0; g < 4; ++g) { v[g] += __shfl_xor(v[g], 16); v[g] += __shfl_xor(v[g], 32); }
+        if (kq == 0) *reinterpret_cast<float4*>(red + 256 + wave * 64 + 4 * j) = make_float4(v[0], v[1], v[2], v[3]);
+        __syncthreads();
+        const float4 q0 = *reinterpret_cast<const float4*>(red + 256 + 4 * j), q1 = *reinterpret_cast<const float4*>(red + 320 + 4 * j);
+        const float4 q2 = *reinterpret_cast<const float4*>(red + 384 + 4 * j), q3 = *reinterpret_cast<const float4*>(red + 448 + 4 * j);
+        rstd[0] = 1.0f / sqrtf((((q0.x + q1.x) + q2.x) + q3.x) * (1.0f / K) + a.ln_eps);
+        rstd[1] = 1.0f / sqrtf((((q0.y + q1.y) + q2.y) + q3.y) * (1.0f / K) + a.ln_eps);
+        rstd[2] = 1.0f / sqrtf((((q0.z + q1.z) + q2.z) + q3.z) * (1.0f / K) + a.ln_eps);
+        rstd[3] = 1.0f / sqrtf((((q0.w + q1.w) + q2.w) + q3.w) * (1.0f / K) + a.ln_eps);
+    }
+    // normalise, split into three bf16 pieces, publish in B-operand order
+#pragma unroll
+    for (int i = 0; i < KPW; ++i) {
+        const int kb = wave * KPW + i;
+        u32x4 bp[4][3];
+#pragma unroll
+        for (int hp = 0; hp < 4; ++hp) {
+            const int k = 32 * kb + 8 * kq + 2 * hp;
+            const float ga = a.ln_w[k], gb = a.ln_w[k + 1];
+            const float ba = a.ln_b ? a.ln_b[k] : 0.f, bb = a.ln_b ? a.ln_b[k + 1] : 0.f;
+            const float xa[4] = {xr[i][2 * hp].x, xr[i][2 * hp].y, xr[i][2 * hp].z, xr[i][2 * hp].w};
+            const float xc[4] = {xr[i][2 * hp + 1].x, xr[i][2 * hp + 1].y, xr[i][2 * hp + 1].z, xr[i][2 * hp + 1].w};
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const float mu = a.ln_b ? mean[g] : 0.f;     // BiasFree_LayerNorm scales x, not x - mean
+                const float ya = fmaf((xa[g] - mu) * rstd[g], ga, ba), yb = fmaf((xc[g] - mu) * rstd[g], gb, bb);
+                unsigned a0, a1, a2, b0, b1, b2;
+                b3_split(ya, a0, a1, a2);
+                b3_split(yb, b0, b1, b2);
+                bp[g][0][hp] = b3_pack(a0, b0);
+                bp[g][1][hp] = b3_pack(a1, b1);
+                bp[g][2][hp] = b3_pack(a2, b2);
+            }
+        }
+#pragma unroll
+        for (int g = 0; g < 4; ++g)
+#pragma unroll
+            for (int pc = 0; pc < 3; ++pc) Bl[((kb * 4 + g) * 3 + pc) * 64 + lane] = bp[g][pc];
+    }
+    __syncthreads();
+    if (PREF && tile + (int)gridDim.x < ntile) load_x(tile + gridDim.x);
+
+    // ---- output tiles of this wave, NCO at a time
+    for (int chunk = 0; chunk * NCO < tpw; ++chunk) {
+        const int t0 = wave * tpw + chunk * NCO;
+        f32x4 acc[NCO][4];
+#pragma unroll
+        for (int t = 0; t < NCO; ++t)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) acc[t][g] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        // A pieces straight from L2, in a ring of RING (K block, tile) steps: a step's three 16-byte loads are issued
+        // RING - 1 steps (x 24 MFMAs = 408 cycles each) before their use.
+        constexpr int RING = KB > 4 ? 12 : 5, STEPS = KB * NCO;
+        u32x4 A[RING][3];
+        auto load_a = [&](int slot, int step) {
+            const int kb = step / NCO, t = step - kb * NCO;
+#pragma unroll
+            for (int pc = 0; pc < 3; ++pc) A[slot][pc] = wp3[((size_t)kb * NT + t0 + t) * 192 + pc * 64];
+        };
+#pragma unroll
+        for (int i = 0; i < RING - 1; ++i) load_a(i, i);
+        // B pieces from LDS, double-buffered per K block: the 12 reads of block kb + 1 are spread over the NCO steps of block kb
+        u32x4 bp[2][4][3];
+        auto load_b = [&](int buf, int kb, int first, int last) {
+#pragma unroll
+            for (int i = first; i < last; ++i) bp[buf][i / 3][i % 3] = Bl[(kb * 12 + i) * 64 + lane];
+        };
+        load_b(0, 0, 0, 12);
+#pragma unroll
+        for (int step = 0; step < STEPS; ++step) {
+            const int kb = step / NCO, t = step % NCO;
+            if (step + RING - 1 < STEPS) load_a((step + RING - 1) % RING, step + RING - 1);
+            if (kb + 1 < KB) load_b((kb + 1) & 1, kb + 1, 12 * t / NCO, 12 * (t + 1) / NCO);
+            b3_mfma4(A[step % RING], bp[kb & 1], acc[t]);
+            __builtin_amdgcn_sched_barrier(0);      // keep the ring: without it hipcc hoists every load to the top and spills
+        }
+        epilogue<NCO, false>(a, acc, t0, NCO, bias_l + 16 * t0, nullptr, b, p0, kq, live);
+    }
+    }   // pixel tiles (the first barrier of the next tile's statistics also frees Bl)
+}
+
+static bool b3_ln_supported(const Conv1x1Args& a, int* nco) {
+    const int K = a.C1 + a.C2;
+    if (!(a.ln_w && a.wp3 && a.C2 == 0 && (K == 128 || K == 256) && a.mode == 0 && !a.res && a.Cout % 64 == 0 && a.Cout <= 1024 &&
+          aligned16(a.wp3) && a.wp3_bstride % 4 == 0))
+        return false;
+    const int tpw = a.Cout / 64;
+    // K = 128 runs two workgroups per CU (256 registers): 4 tiles at once plus the next pixel tile in flight would spill
+    *nco = (K == 256 && tpw % 4 == 0) ? 4 : tpw % 3 == 0 ? 3 : tpw % 2 == 0 ? 2 : 0;
+    return *nco != 0;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -704,6 +864,23 @@ int launch_conv1x1(const Conv1x1Args& a, hipStream_t st) {
         int gx = cdiv(a.P, 256);
         if (gx > 4096) gx = 4096;
         conv1x1_scalar_kernel<<<dim3((unsigned)gx, (unsigned)a.B), 256, 0, st>>>(a);
+    } else if (int nco_ln = 0; use_b3 && b3_ln_supported(a, &nco_ln)) {
+        const int kb = K / 32, tpw = a.Cout / 64;
+        const int slots = (kb == 4 ? 2 : 1) * 256;                // resident workgroups (LDS: 55 KB / 104 KB)
+        int gx = slots / a.B;
+        gx = gx < 1 ? 1 : gx;
+        gx = gx < cdiv(a.P, 64) ? gx : cdiv(a.P, 64);
+        dim3 grid((unsigned)gx, (unsigned)a.B, 1);
+        snprintf(key, sizeof(key), "conv1x1_b3_ln_kernel<%d, %d>", kb, nco_ln);
+        ProfScope prof(st, key, work_flops, work_bytes);
+        if (kb == 4) {
+            if (nco_ln == 3) conv1x1_b3_ln_kernel<4, 3><<<grid, 256, 0, st>>>(a, tpw);
+            else conv1x1_b3_ln_kernel<4, 2><<<grid, 256, 0, st>>>(a, tpw);
+        } else {
+            if (nco_ln == 4) conv1x1_b3_ln_kernel<8, 4><<<grid, 256, 0, st>>>(a, tpw);
+            else if (nco_ln == 3) conv1x1_b3_ln_kernel<8, 3><<<grid, 256, 0, st>>>(a, tpw);
+            else conv1x1_b3_ln_kernel<8, 2><<<grid, 256, 0, st>>>(a, tpw);
+        }
     } else if (use_b3) {
         // bf16x3 streaming kernel (K > 32: below that the resident-input f32 kernels are HBM-bound anyway)
         // 6 tiles per workgroup where that divides the output evenly; never with the LayerNorm prologue (that instantiation

@@ -134,11 +134,11 @@ def issued_over_algorithmic(kernel: str) -> float:
     f32 product (three-piece split of both operands)."""
     if kernel.startswith("conv3x3_kernel"):
         return 0.5
-    return 6.0 if kernel.startswith("conv1x1_b3_kernel") else 1.0
+    return 6.0 if kernel.startswith("conv1x1_b3_") else 1.0
 
 
 def pipe_peak(kernel: str) -> float:
-    return PEAK_BF16_MFMA_TFLOPS if kernel.startswith("conv1x1_b3_kernel") else PEAK_F32_MFMA_TFLOPS
+    return PEAK_BF16_MFMA_TFLOPS if kernel.startswith("conv1x1_b3_") else PEAK_F32_MFMA_TFLOPS
 
 
 def roofline_of(rec):
