@@ -23,6 +23,8 @@ class RfConfig(C.Structure):
 
 
 _vp, _i, _f, _sz = C.c_void_p, C.c_int, C.c_float, C.c_size_t
+# rf_allreduce_fn (include/rawformer_hip.h): void (*)(void* user, float* buf, size_t n, int op, void* stream); buf arrives as an integer address
+ALLREDUCE_FN = C.CFUNCTYPE(None, C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_void_p)
 _psz = C.POINTER(C.c_size_t)
 
 # name -> (restype, argtypes); mirrors include/rawformer_hip.h one to one
@@ -41,6 +43,7 @@ SIGNATURES = {
     "rf_workspace_bytes": (_i, [_vp, _i, _i, _i, _psz]),
     "rf_forward": (_i, [_vp, _vp, _vp, _vp, _sz, _i, _i, _i, _i, _vp]),
     "rf_forward_stage": (_i, [_vp, _i, _vp, _vp, _vp, _vp, _sz, _i, _i, _i, _vp]),
+    "rf_set_shard": (_i, [_vp, _i, _i, _i, ALLREDUCE_FN, _vp]),
     "rf_flat_param_floats": (_i, [_vp, _psz]),
     "rf_flat_offset": (_i, [_vp, _i, _psz]),
     "rf_train_workspace_bytes": (_i, [_vp, _i, _i, _i, _psz]),

@@ -67,8 +67,12 @@ __global__ void __launch_bounds__(256) gram_kernel(GramArgs a, int vec) {
     band_of(tq, C, c, &tklo, &nb);
     const float* qb = a.q + (size_t)b * a.bstride;
     const float* kb = a.k + (size_t)b * a.bstride;
-    const int n_lo = slab_id * a.slab;
-    const int n_hi = (n_lo + a.slab < P) ? n_lo + a.slab : P;
+    // the slab's pixels, cut to the rows that enter the statistics (a spatial shard counts its interior rows only)
+    const int m_hi = a.p_hi > 0 ? a.p_hi : P;
+    int n_lo = slab_id * a.slab;
+    int n_hi = (n_lo + a.slab < m_hi) ? n_lo + a.slab : m_hi;
+    if (n_lo < a.p_lo) n_lo = a.p_lo;
+    if (n_hi < n_lo) n_hi = n_lo;
 
     f32x4 g[kMaxBand], nq = {0.f, 0.f, 0.f, 0.f}, nk = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll

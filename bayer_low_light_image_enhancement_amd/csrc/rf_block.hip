@@ -50,11 +50,14 @@ int run_transformer(const TbParams& p, const float* in, float* out, float* ws, c
     // x + attn(LN1(x)) ---------------------------------------------------------------------
     Conv1x1Args av{};
     int nslab = 0;
+    size_t partial_floats = 0;
     if (!no_fuse_attn && fused_attn_supported(C, heads, hh, ww)) {
         // LN1 -> qkv 1x1 -> depthwise 3x3 -> {Gram partials, v} in one kernel: qkv never reaches HBM
         size_t pf;
         RF_TRY(fused_attn_plan(hh, ww, &nslab, &pf, B, C));
-        RF_TRY(launch_attn_front(in, bufB, partial, nslab, p.ln1_w, p.ln1_b, p.qkv_wp3, p.qkv_b, p.qkv_dw_w, p.qkv_dw_b, B, C, hh, ww, st));
+        RF_TRY(launch_attn_front(in, bufB, partial, nslab, p.ln1_w, p.ln1_b, p.qkv_wp3, p.qkv_b, p.qkv_dw_w, p.qkv_dw_b, B, C, hh, ww, st,
+                                 p.ylo, p.yhi));
+        partial_floats = pf;
         av.x1 = bufB; av.x1_bstride = (int64_t)C * Pn;
     } else {
         Conv1x1Args q{};
@@ -68,7 +71,8 @@ int run_transformer(const TbParams& p, const float* in, float* out, float* ws, c
             // depthwise 3x3 of q, k, v + Gram partials in one kernel: dw(q), dw(k) never reach HBM
             size_t pf;
             RF_TRY(attn_mid_plan(hh, ww, &nslab, &pf, B, C));
-            RF_TRY(launch_attn_mid(bufA, bufB, partial, nslab, p.qkv_dw_w, p.qkv_dw_b, B, C, hh, ww, st));
+            RF_TRY(launch_attn_mid(bufA, bufB, partial, nslab, p.qkv_dw_w, p.qkv_dw_b, B, C, hh, ww, st, p.ylo, p.yhi));
+            partial_floats = pf;
             av.x1 = bufB; av.x1_bstride = (int64_t)C * Pn;
         } else {
         DwConvArgs d{};
@@ -82,11 +86,16 @@ int run_transformer(const TbParams& p, const float* in, float* out, float* ws, c
         g.B = B; g.C = C; g.heads = heads; g.P = Pn; g.partial = partial;
         size_t pf;
         RF_TRY(gram_plan(B, C, heads, Pn, &g.nslab, &g.slab, &pf));
+        g.p_lo = p.ylo * ww; g.p_hi = p.yhi * ww;
         RF_TRY(launch_gram(g, st));
         nslab = g.nslab;
+        partial_floats = pf;
         av.x1 = bufB + (size_t)2 * C * Pn; av.x1_bstride = (int64_t)3 * C * Pn;
         }
     }
+    // spatial shard: every rank holds the same slab grid (equal local shapes), so the element-wise sum of the partial buffers is
+    // the partial buffer of the whole frame; the fold then sums the slabs as always
+    if (p.allreduce) p.allreduce(p.allreduce_user, partial, partial_floats, 0, (void*)st);
     RF_TRY(launch_attn_fold(partial, nslab, p.temperature, p.proj_w, wfold, wfold3, B, C, heads, st, p.log_temperature));
     av.C1 = C;
     av.wp = wfold; av.wp_bstride = (int64_t)packed1x1_floats(C, C);

@@ -221,6 +221,7 @@ struct GramArgs {
     int B, C, heads, P;
     float* partial;                   // [B][nslab][C][bandw + 2]  (see gram_partial_floats)
     int nslab, slab;
+    int p_lo = 0, p_hi = 0;           // pixels [p_lo, p_hi) enter the statistics (p_hi = 0: all); see rf_set_shard
 };
 int gram_plan(int B, int C, int heads, int P, int* nslab, int* slab, size_t* partial_floats);
 int launch_gram(const GramArgs& a, hipStream_t st);
@@ -236,13 +237,14 @@ int launch_ffn_fused(const float* x, float* out, const float* ln_w, const float*
 bool fused_attn_supported(int C, int heads, int h, int w);
 int fused_attn_plan(int h, int w, int* nslab, size_t* partial_floats, int B, int C);
 int launch_attn_front(const float* x, float* v, float* partial, int nslab, const float* ln_w, const float* ln_b,
-                      const void* wp /* b3 */, const float* bq, const float* wd, const float* bd, int B, int C, int h, int w, hipStream_t st);
+                      const void* wp /* b3 */, const float* bq, const float* wd, const float* bd, int B, int C, int h, int w, hipStream_t st,
+                      int ylo = 0, int yhi = 0 /* rows [ylo, yhi) enter the Gram statistics; yhi = 0: all */);
 
 // qkv [B,3C,h,w] -> depthwise 3x3 -> Gram partials of (q,k) + v, for C = 64 / 128
 bool attn_mid_supported(int C, int heads, int h, int w);
 int attn_mid_plan(int h, int w, int* nslab, size_t* partial_floats, int B, int C);
 int launch_attn_mid(const float* qkv, float* v, float* partial, int nslab, const float* wd, const float* bd,
-                    int B, int C, int h, int w, hipStream_t st);
+                    int B, int C, int h, int w, hipStream_t st, int ylo = 0, int yhi = 0);
 
 // ---- TransformerBlock schedule (rf_block.hip)
 struct TbParams {
@@ -251,6 +253,11 @@ struct TbParams {
     const float *ln2_w, *ln2_b, *pw1_wp /* packed */, *pw1_b, *dw_w, *dw_b, *pw2_wp /* packed */, *pw2_b;
     const void *qkv_wp3, *pw1_wp3, *pw2_wp3;   // b3 forms of the three packed weights (nullptr: f32 kernels only)
     int log_temperature;                       // `temperature` holds log T (TrueColorRawFormer, BayerTORGBColorMultiLvl.py:331,344)
+    // spatial shard (rf_set_shard): rows [ylo, yhi) of this level enter the Gram statistics, and `allreduce` sums the
+    // slab partials over the ranks before the softmax (nullptr: single device)
+    int ylo = 0, yhi = 0;
+    void (*allreduce)(void* user, float* buf, size_t n, int op, void* stream) = nullptr;
+    void* allreduce_user = nullptr;
 };
 struct TbBufOffsets { size_t bufA, bufB, x1, partial, wfold, wfold3; };   // float offsets into one scratch area
 size_t transformer_scratch_floats(int B, int C, int heads, int hc, int h, int w, TbBufOffsets* o);
@@ -303,7 +310,8 @@ int launch_flca_backward(const float* feat, const float* guide, const float* xs,
 // ---- FLCA (rf_flca.hip)
 size_t guidance_scratch_floats(int B, int H, int W);
 // packed-or-mosaic input -> base planes in scratch (y, cr, cb at HxW; LL, mag at H/2 x W/2)
-int launch_guidance_base(const float* in, int mosaic, int clamp_in, float* scratch, int B, int H, int W, hipStream_t st);
+int launch_guidance_base(const float* in, int mosaic, int clamp_in, float* scratch, int B, int H, int W, hipStream_t st,
+                         void (*allreduce)(void*, float*, size_t, int, void*) = nullptr, void* allreduce_user = nullptr);
 int launch_guidance_level(const float* scratch, float* guide, int B, int H, int W, int hf, int wf, hipStream_t st);
 struct FlcaSpatialArgs {
     const float* feat; float* xs; const float* guide;   // feat/xs [B][C][P], guide [B][4][h][w]
@@ -311,6 +319,7 @@ struct FlcaSpatialArgs {
     const float* alpha; const float* beta; const float* gamma;     // device scalars
     float* partial;                                      // [B][nblk][C] per-block channel sums
     int B, C, h, w, nblk;
+    int ylo = 0, yhi = 0;                                // rows [ylo, yhi) enter the channel sums (yhi = 0: all); see rf_set_shard
 };
 int flca_nblk(int h, int w);
 int launch_flca_spatial(const FlcaSpatialArgs& a, hipStream_t st);

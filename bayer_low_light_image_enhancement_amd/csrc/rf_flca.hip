@@ -103,7 +103,8 @@ __global__ void __launch_bounds__(256) guide_haar_kernel(const float* __restrict
     }
 }
 
-int launch_guidance_base(const float* in, int mosaic, int clamp_in, float* scratch, int B, int H, int W, hipStream_t st) {
+int launch_guidance_base(const float* in, int mosaic, int clamp_in, float* scratch, int B, int H, int W, hipStream_t st,
+                         void (*allreduce)(void*, float*, size_t, int, void*), void* allreduce_user) {
     RF_CHECK_ARG(H % 2 == 0 && W % 2 == 0 && B <= 65535, "guidance: H=%d W=%d must be even", H, W);
     const GuideLayout g = guide_layout(scratch, B, H, W);
     ProfScope prof(st, "guidance_base(3 kernels)", 0.0, 4.0 * B * H * W * (4 + 1 + 1 + 4 + 3.5));
@@ -113,6 +114,9 @@ int launch_guidance_base(const float* in, int mosaic, int clamp_in, float* scrat
     const int cap = 2048 / B > 32 ? 2048 / B : 32;   // grid-stride: few workgroups (= few atomics) per image
     if (gx > cap) gx = cap;
     guide_luma_kernel<<<dim3((unsigned)gx, (unsigned)B), 256, 0, st>>>(in, mosaic, clamp_in, g.y, g.amax, H, W);
+    // spatial shard: the luma normaliser is the maximum over the whole frame = the max over the ranks' windows (the stored bit
+    // patterns are the floats themselves)
+    if (allreduce) allreduce(allreduce_user, reinterpret_cast<float*>(g.amax), (size_t)B, 1, (void*)st);
     int gx2 = (int)((hw / 4 + 255) / 256);
     if (gx2 > 1024) gx2 = 1024;
     guide_haar_kernel<<<dim3((unsigned)gx2, (unsigned)B), 256, 0, st>>>(in, mosaic, clamp_in, scratch, B, H, W);
@@ -179,6 +183,7 @@ __global__ void __launch_bounds__(256) flca_spatial_vec_kernel(FlcaSpatialArgs a
     const int p = (blk * 256 + threadIdx.x) * 4;
     const bool live = p < P;
     const int y = live ? p / w : 0, x = live ? p - (p / w) * w : 0;
+    const bool counted = y >= a.ylo && y < (a.yhi > 0 ? a.yhi : h);      // rows of the squeeze-excite pooling
     float nb[4][3][6];
     const float* gb = a.guide + b * 4 * (size_t)P;
 #pragma unroll
@@ -227,7 +232,7 @@ __global__ void __launch_bounds__(256) flca_spatial_vec_kernel(FlcaSpatialArgs a
         float s = 0.f;
         if (live) {
             *reinterpret_cast<float4*>(xb + (size_t)c * P) = make_float4(v[0], v[1], v[2], v[3]);
-            s = (v[0] + v[1]) + (v[2] + v[3]);
+            if (counted) s = (v[0] + v[1]) + (v[2] + v[3]);
         }
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
@@ -246,6 +251,7 @@ __global__ void __launch_bounds__(256) flca_spatial_kernel(FlcaSpatialArgs a) {
     const int p = blk * 256 + threadIdx.x;
     const bool live = p < P;
     const int y = live ? p / w : 0, x = live ? p % w : 0;
+    const bool counted = y >= a.ylo && y < (a.yhi > 0 ? a.yhi : h);
     // 3x3 neighbourhoods of the four guidance planes, zero padded
     float nb[4][9];
     const float* gb = a.guide + b * 4 * (size_t)P;
@@ -278,6 +284,7 @@ __global__ void __launch_bounds__(256) flca_spatial_kernel(FlcaSpatialArgs a) {
         if (live) {
             v = fb[(size_t)c * P + p] * (1.0f + al * fast_sigmoid(sl) + be * fast_tanh(sh) + ga * fast_sigmoid(sc));
             xb[(size_t)c * P + p] = v;
+            if (!counted) v = 0.f;
         }
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);

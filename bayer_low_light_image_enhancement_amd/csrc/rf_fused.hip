@@ -471,6 +471,7 @@ struct AttnFrontArgs {
     const float* wd;       // [3C][9]
     const float* bd;       // [3C]
     int B, h, w, tiles_x, ntiles, nslab;
+    int ylo, yhi;          // rows [ylo, yhi) enter the Gram statistics (a spatial shard's interior; the whole image otherwise)
 };
 
 template <int C>
@@ -540,7 +541,7 @@ __global__ void __launch_bounds__(256, 2) attn_front_kernel(AttnFrontArgs a) {
 #pragma unroll 1                                         // unrolled, the hoisted stencil loads push the kernel into scratch
             for (int st = 0; st < 4; ++st) {
                 const int xo = x0 + 16 * st + 4 * kq;
-                const bool ok = yo < h && xo < w;
+                const bool ok = yo >= a.ylo && yo < a.yhi && xo < w;
                 float qa[4], kb[4];
                 stencil4_wide(mid + j * PSG + wave * HC + 16 * st + 4 * kq + 4, wd_l + cq * 9, bd_l[cq], qa);
                 stencil4_wide(mid + (16 + j) * PSG + wave * HC + 16 * st + 4 * kq + 4, wd_l + ck * 9, bd_l[ck], kb);
@@ -637,10 +638,11 @@ int fused_attn_plan(int h, int w, int* nslab, size_t* partial_floats, int B, int
 }
 
 int launch_attn_front(const float* x, float* v, float* partial, int nslab, const float* ln_w, const float* ln_b,
-                      const void* wp, const float* bq, const float* wd, const float* bd, int B, int C, int h, int w, hipStream_t st) {
+                      const void* wp, const float* bq, const float* wd, const float* bd, int B, int C, int h, int w, hipStream_t st,
+                      int ylo, int yhi) {
     RF_CHECK_ARG(C == 32 && w % 4 == 0 && B <= 65535, "attn_front: unsupported shape C=%d %dx%d", C, h, w);
     RF_CHECK_ARG(aligned16(x) && aligned16(v), "attn_front: buffers must be 16-byte aligned");
-    AttnFrontArgs a{x, v, partial, ln_w, ln_b, wp, bq, wd, bd, B, h, w, cdiv(w, fused::TW), 0, nslab};
+    AttnFrontArgs a{x, v, partial, ln_w, ln_b, wp, bq, wd, bd, B, h, w, cdiv(w, fused::TW), 0, nslab, ylo, (yhi > 0 && yhi < h) ? yhi : h};
     a.ntiles = a.tiles_x * cdiv(h, fused::TH);
     const double px = (double)B * h * w;
     ProfScope prof(st, "attn_front_kernel<32>", px * (6.0 * C * C + 54.0 * C + 4.0 * C * 16), px * 8.0 * C);
@@ -665,6 +667,7 @@ struct AttnMidArgs {
     const float* wd;       // [3C][9]
     const float* bd;       // [3C]
     int B, h, w, tiles_x, ntiles, nslab;
+    int ylo, yhi;          // as AttnFrontArgs
 };
 
 template <int C>
@@ -765,7 +768,7 @@ __global__ void __launch_bounds__(256, 2) attn_mid_kernel(AttnMidArgs a) {
 #pragma unroll
                 for (int st = 0; st < 4; ++st) {
                     const int xo = x0 + 16 * st + 4 * kq;
-                    const bool ok = yo < h && xo < w;
+                    const bool ok = yo >= a.ylo && yo < a.yhi && xo < w;
                     float qa[4], kb[4];
                     stencil4_wide(mid + j * PSG + wave * HC + 16 * st + 4 * kq + 4, wd_l + cq * 9, bd_l[cq], qa);
                     stencil4_wide(mid + (16 + j) * PSG + wave * HC + 16 * st + 4 * kq + 4, wd_l + ck * 9, bd_l[ck], kb);
@@ -832,10 +835,10 @@ bool attn_mid_supported(int C, int heads, int h, int w) {
 }
 
 int launch_attn_mid(const float* qkv, float* v, float* partial, int nslab, const float* wd, const float* bd,
-                    int B, int C, int h, int w, hipStream_t st) {
+                    int B, int C, int h, int w, hipStream_t st, int ylo, int yhi) {
     RF_CHECK_ARG((C == 64 || C == 128) && w % 4 == 0 && B <= 65535, "attn_mid: unsupported shape C=%d %dx%d", C, h, w);
     RF_CHECK_ARG(aligned16(qkv) && aligned16(v), "attn_mid: buffers must be 16-byte aligned");
-    AttnMidArgs a{qkv, v, partial, wd, bd, B, h, w, cdiv(w, fused::TW), 0, nslab};
+    AttnMidArgs a{qkv, v, partial, wd, bd, B, h, w, cdiv(w, fused::TW), 0, nslab, ylo, (yhi > 0 && yhi < h) ? yhi : h};
     a.ntiles = a.tiles_x * cdiv(h, fused::TH);
     const double px = (double)B * h * w;
     ProfScope prof(st, C == 64 ? "attn_mid_kernel<64>" : "attn_mid_kernel<128>", px * (54.0 * C + 4.0 * C * 16), px * 16.0 * C);

@@ -38,6 +38,11 @@ struct rf_handle {
     const float* packed = nullptr;   // caller memory, valid after rf_pack_params
     std::vector<size_t> flat_offset;  // float offset of every parameter in the flat parameter / gradient buffers (training)
     size_t flat_floats = 0;
+    // spatial shard of one frame (rf_set_shard): interior rows [y_lo, y_hi) of the local window and the frame's total rows, in
+    // packed (level-0) rows; `allreduce` sums a float buffer over the ranks on the given stream
+    int shard_y_lo = 0, shard_y_hi = 0, shard_total_rows = 0;
+    void (*shard_allreduce)(void* user, float* buf, size_t n, int op, void* stream) = nullptr;
+    void* shard_user = nullptr;
 };
 
 

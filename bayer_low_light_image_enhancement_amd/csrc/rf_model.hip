@@ -226,6 +226,11 @@ int run_stage(const rf_handle* h, int i, int lvl, const float* in, float* out, f
     tp.pw2_wp = PK(h, t + "ffn.pointwise2.weight"); tp.pw2_b = P(h, t + "ffn.pointwise2.bias");
     tp.qkv_wp3 = PK3(h, t + "attn.qkv.weight"); tp.pw1_wp3 = PK3(h, t + "ffn.pointwise1.weight"); tp.pw2_wp3 = PK3(h, t + "ffn.pointwise2.weight");
     if (cfg.variant == RF_VARIANT_TRUECOLOR) { tp.temperature = P(h, t + "attn.log_temperature"); tp.log_temperature = 1; }
+    // spatial shard: this level's interior rows and the frame's pixel count for the pooled mean
+    const bool sharded = h->shard_allreduce != nullptr;
+    const int ylo = sharded ? h->shard_y_lo >> lvl : 0, yhi = sharded ? h->shard_y_hi >> lvl : 0;
+    const int P_pool = sharded ? (h->shard_total_rows >> lvl) * ww : Pn;
+    if (sharded) { tp.ylo = ylo; tp.yhi = yhi; tp.allreduce = h->shard_allreduce; tp.allreduce_user = h->shard_user; }
     TbBufOffsets to{p.bufA, p.bufB, p.x1, p.gram_partial, p.wfold_attn, p.wfold_attn3};
     RF_TRY(run_transformer(tp, in, trans, ws, to, B, C, heads, hc, hh, ww, st));
 
@@ -264,9 +269,11 @@ int run_stage(const rf_handle* h, int i, int lvl, const float* in, float* out, f
         s.w_low = P(h, f + "low_attn.0.weight"); s.w_high = P(h, f + "high_attn.0.weight"); s.w_chr = P(h, f + "chroma_attn.0.weight");
         s.alpha = P(h, f + "alpha"); s.beta = P(h, f + "beta"); s.gamma = P(h, f + "gamma");
         s.partial = ws + p.flca_partial; s.B = B; s.C = C; s.h = hh; s.w = ww; s.nblk = flca_nblk(hh, ww);
+        s.ylo = ylo; s.yhi = yhi;
         RF_TRY(launch_flca_spatial(s, st));
+        if (sharded) h->shard_allreduce(h->shard_user, s.partial, (size_t)B * s.nblk * C, 0, (void*)st);
         const int hid = C / 8 > 8 ? C / 8 : 8;
-        RF_TRY(launch_flca_se_fold(s.partial, s.nblk, Pn, P(h, f + "se.1.weight"), P(h, f + "se.1.bias"),
+        RF_TRY(launch_flca_se_fold(s.partial, s.nblk, P_pool, P(h, f + "se.1.weight"), P(h, f + "se.1.bias"),
                                    P(h, f + "se.3.weight"), P(h, f + "se.3.bias"), hid, P(h, pre + "channel_reduce.weight"),
                                    ws + p.wfold_cr, ws + p.wfold_cr3, ws + p.ch, B, C, st));
         r.wp = ws + p.wfold_cr; r.wp_bstride = (int64_t)packed1x1_floats(2 * C, C);
@@ -457,6 +464,21 @@ int rf_workspace_bytes(const rf_handle* h, int B, int H, int W, size_t* bytes) {
     return RF_OK;
 }
 
+int rf_set_shard(rf_handle* h, int y_lo, int y_hi, int total_rows, rf_allreduce_fn allreduce, void* user) {
+    RF_CHECK_ARG(h, "rf_set_shard: null handle");
+    if (!allreduce) {
+        h->shard_y_lo = h->shard_y_hi = h->shard_total_rows = 0;
+        h->shard_allreduce = nullptr; h->shard_user = nullptr;
+        return RF_OK;
+    }
+    RF_CHECK_ARG(h->cfg.variant != RF_VARIANT_TRUECOLOR, "rf_set_shard: variants flca and plain only");
+    RF_CHECK_ARG(y_lo >= 0 && y_hi > y_lo && y_lo % 8 == 0 && y_hi % 8 == 0 && total_rows >= y_hi - y_lo && total_rows % 8 == 0,
+                 "rf_set_shard: interior rows [%d, %d) of %d must be multiples of 8", y_lo, y_hi, total_rows);
+    h->shard_y_lo = y_lo; h->shard_y_hi = y_hi; h->shard_total_rows = total_rows;
+    h->shard_allreduce = allreduce; h->shard_user = user;
+    return RF_OK;
+}
+
 int rf_forward_stage(rf_handle* h, int stage, const float* in, const float* packed, float* out, void* workspace,
                      size_t workspace_bytes, int B, int H, int W, void* stream) {
     RF_CHECK_ARG(h && in && out && workspace && stage >= 1 && stage <= 7, "rf_forward_stage: bad arguments (stage 1..7)");
@@ -496,6 +518,8 @@ int rf_forward(rf_handle* h, const float* in, float* out, void* workspace, size_
         return RF_E_MISSING;
     }
     RF_CHECK_ARG(aligned16(workspace) && aligned16(in) && aligned16(out), "rf_forward: buffers must be 16-byte aligned");
+    RF_CHECK_ARG(!h->shard_allreduce || h->shard_y_hi <= H, "rf_forward: shard interior [%d, %d) outside the %d-row window",
+                 h->shard_y_lo, h->shard_y_hi, H);
     Plan p;
     RF_TRY(make_plan(h, B, H, W, p));
     if (workspace_bytes < p.total * sizeof(float)) {
@@ -510,7 +534,7 @@ int rf_forward(rf_handle* h, const float* in, float* out, void* workspace, size_
 
     const int levels = cfg.flca_levels > 0 ? cfg.flca_levels : 2;
     if (cfg.variant == RF_VARIANT_FLCA) {
-        RF_TRY(launch_guidance_base(in, mosaic, cfg.clamp_io, ws + p.gscratch, B, H, W, st));
+        RF_TRY(launch_guidance_base(in, mosaic, cfg.clamp_io, ws + p.gscratch, B, H, W, st, h->shard_allreduce, h->shard_user));
         for (int l = 0; l < 4; ++l)
             RF_TRY(launch_guidance_level(ws + p.gscratch, ws + p.guide[l], B, H, W, H >> l, W >> l, st));
     } else if (cfg.variant == RF_VARIANT_TRUECOLOR) {

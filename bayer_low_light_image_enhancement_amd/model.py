@@ -328,6 +328,50 @@ class RawFormer(nn.Module):
                                       int(packed_input), stream), "rf_forward")
         return out
 
+    def forward_window(self, x: torch.Tensor, y_lo: int, y_hi: int, total_rows: int, group=None) -> torch.Tensor:
+        """Forward of one rank's WINDOW of a spatially sharded frame (``tiling.forward_full_frame_exact``; C ABI
+        ``rf_set_shard``).  ``x``: the window of the mosaic ``[B,1,2Hl,2Wl]``, the same shape on every rank of ``group``;
+        ``[y_lo, y_hi)``: this rank's interior rows inside the window and ``total_rows`` the frame's height, in PACKED rows
+        (mosaic rows / 2, multiples of 8).  The channel attention's Gram statistics and FLCA's squeeze-excite pooling are
+        taken over interior rows and all-reduced over ``group`` (RCCL with the ``nccl`` backend), so interior rows of the
+        result equal the whole-frame forward up to summation order when the window reaches ``tiling.HALO_ROWS`` rows beyond
+        the interior (or the frame border).  Rows outside the interior are meaningless."""
+        import torch.distributed as dist
+
+        if self.variant == "truecolor":
+            raise RuntimeError("forward_window: variants 'flca' and 'plain' only")
+        lib = _lib.load()
+        failure: List[BaseException] = []
+
+        def allreduce(_user, buf, n, op, _stream):
+            try:
+                ws = self._state_for(x.device).workspace
+                off = buf - ws.data_ptr()
+                if off < 0 or off % 4 or off + 4 * n > ws.numel():
+                    raise RuntimeError("all-reduce buffer outside the workspace")
+                view = ws[off: off + 4 * n].view(torch.float32)
+                dist.all_reduce(view, op=dist.ReduceOp.MAX if op == 1 else dist.ReduceOp.SUM, group=group)      # ordered on torch's current stream = `stream`
+            except BaseException as e:  # noqa: BLE001 - a ctypes callback cannot raise; re-raised below
+                failure.append(e)
+
+        cb = _lib.ALLREDUCE_FN(allreduce)
+        with torch.cuda.device(x.device):
+            st = self._state_for(x.device)
+            # the workspace must exist (and not move) before the callback sees pointers into it
+            sz = C.c_size_t()
+            _lib.check(lib.rf_workspace_bytes(st.handle, x.shape[0], x.shape[2] // 2, x.shape[3] // 2, C.byref(sz)), "rf_workspace_bytes")
+            if st.workspace is None or st.workspace.numel() < sz.value:
+                st.workspace = None
+                st.workspace = torch.empty(sz.value, dtype=torch.uint8, device=x.device)
+            _lib.check(lib.rf_set_shard(st.handle, int(y_lo), int(y_hi), int(total_rows), cb, None), "rf_set_shard")
+            try:
+                out = self._run(x, packed_input=False)
+            finally:
+                lib.rf_set_shard(st.handle, 0, 0, 0, _lib.ALLREDUCE_FN(0), None)
+        if failure:
+            raise failure[0]
+        return out
+
     def forward(self, x: torch.Tensor) -> torch.Tensor:
         """Mosaic ``[B, inp_channels, 2H, 2W]`` -> ``[B, out_channels, 2H, 2W]`` (test.py:116)."""
         return self._run(x, packed_input=False)

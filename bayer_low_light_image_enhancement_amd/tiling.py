@@ -10,6 +10,10 @@ everywhere (attention, squeeze-excite and the luma maximum reduce over ONE image
   the parity oracle for tiled mode is *the same forward run on the same tiles*
   (SURVEY.md section 8e), not the whole-frame forward.
 
+``forward_full_frame_exact`` is the exact alternative: row shards with ``HALO_ROWS`` rows of recomputed context whose global
+statistics are all-reduced inside the forward (``RawFormer.forward_window``, C ABI ``rf_set_shard``), so the stitched frame
+equals the whole-frame forward up to summation order.
+
 ``forward_full_frame_sharded`` runs rank r's tiles on rank r and stitches the sRGB frame on
 every rank with ONE all-gather of fixed-size tile outputs (RCCL over xGMI with the ``nccl``
 backend; ``gloo`` in the CPU tests).  Nothing here touches the HIP library: the per-tile
@@ -129,4 +133,71 @@ def forward_full_frame_sharded(forward: Callable[[torch.Tensor], torch.Tensor], 
         r, slot = idx % world, idx // world
         cy, cx, ch, cw = t.crop
         out[:, :, t.dst[0]:t.dst[0] + ch, t.dst[1]:t.dst[1] + cw] = gathered[r, slot, :, :, cy:cy + ch, cx:cx + cw]
+    return out
+
+
+# ---- exact row sharding ---------------------------------------------------------------------------------------------
+# Receptive field of RawFormer along one axis, in packed (level-0) rows per side, when the global statistics are exact:
+# embedding 3x3 (1) + per stage {qkv depthwise 3x3, FFN depthwise 3x3, Conv_out 3x3} = 3 rows of its level + each
+# down-sampling 3x3 (1 row of its level): encoder 5 + 4*2 + 4*4 + 3*8, decoder 3*4 + 3*2 + 3, output 3x3 1 -> 75; FLCA's
+# guidance 3x3s sit in parallel with the TransformerBlock (1 row of their level).  80 = the next multiple of 8.
+HALO_ROWS = 80
+
+
+@dataclass(frozen=True)
+class RowShard:
+    """One rank's share of a frame, in PACKED rows (mosaic rows / 2)."""
+    start: int      # first row of the window the rank runs
+    rows: int       # window height (equal on all ranks)
+    y_lo: int       # interior rows [y_lo, y_hi) inside the window ...
+    y_hi: int
+    dst: int        # ... which are rows [dst, dst + y_hi - y_lo) of the frame
+
+
+def plan_row_shards(packed_rows: int, world: int, halo: int = HALO_ROWS) -> List[RowShard]:
+    """Cut ``packed_rows`` (a multiple of 8: every U-Net level then has whole rows per shard) into ``world`` interiors on
+    8-row boundaries, each inside an equally tall window that extends ``halo`` rows beyond the interior or to the frame
+    border.  Equal windows give every rank the same slab grid, which is what lets the partial-sum buffers be all-reduced
+    element-wise."""
+    if packed_rows % 8 or halo % 8 or halo < 0:
+        raise ValueError("packed rows and halo must be multiples of 8")
+    units = packed_rows // 8
+    if world < 1 or units < world:
+        raise ValueError(f"{packed_rows} packed rows cannot be cut into {world} shards of at least 8 rows")
+    base, extra = divmod(units, world)
+    bounds = [0]
+    for r in range(world):
+        bounds.append(bounds[-1] + 8 * (base + (1 if r < extra else 0)))
+    rows = min(packed_rows, 8 * (base + (1 if extra else 0)) + 2 * halo)
+    shards = []
+    for r in range(world):
+        r0, r1 = bounds[r], bounds[r + 1]
+        start = min(max(r0 - halo, 0), packed_rows - rows)
+        shards.append(RowShard(start, rows, r0 - start, r1 - start, r0))
+    return shards
+
+
+def forward_full_frame_exact(model, x: torch.Tensor, group=None, halo: int = HALO_ROWS) -> torch.Tensor:
+    """Row-sharded full-frame forward whose result equals the whole-frame forward (up to fp32 summation order): rank r runs
+    ``model.forward_window`` on its window of the mosaic ``x`` ``[B,1,h,w]`` (h divisible by 16), the statistics are
+    all-reduced inside the forward, and one all-gather of the interior strips stitches the sRGB frame on every rank."""
+    import torch.distributed as dist
+
+    world, rank = dist.get_world_size(group), dist.get_rank(group)
+    b, _, h, w = x.shape
+    if h % 16:
+        raise ValueError(f"mosaic height {h} must be divisible by 16")
+    shards = plan_row_shards(h // 2, world, halo)
+    me = shards[rank]
+    win = x[:, :, 2 * me.start: 2 * (me.start + me.rows), :].contiguous()
+    o = model.forward_window(win, me.y_lo, me.y_hi, h // 2, group=group)
+    mh = max(s.y_hi - s.y_lo for s in shards)
+    mine = o.new_zeros((b, o.shape[1], 2 * mh, w))
+    mine[:, :, : 2 * (me.y_hi - me.y_lo)] = o[:, :, 2 * me.y_lo: 2 * me.y_hi]
+    gathered = o.new_empty((world,) + tuple(mine.shape))
+    dist.all_gather_into_tensor(gathered.view(world * b, o.shape[1], 2 * mh, w), mine, group=group)
+    out = o.new_empty((b, o.shape[1], h, w))
+    for r, s in enumerate(shards):
+        n = 2 * (s.y_hi - s.y_lo)
+        out[:, :, 2 * s.dst: 2 * s.dst + n] = gathered[r, :, :, :n]
     return out

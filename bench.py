@@ -20,6 +20,9 @@ Multi-GPU (one process per GPU, RCCL):
     into N overlapping tiles (multiples of 64 mosaic px), rank r runs tile r and ONE all-gather of the
     tile outputs stitches the sRGB frame on every rank -- the collective is INSIDE the timed region
     (strong scaling: the frame is fixed).
+  * cfg4x: the same frame in N exact row shards (tiling.forward_full_frame_exact / rf_set_shard): 80 packed rows of recomputed
+    context per side, the Gram / squeeze-excite / luma-max statistics all-reduced inside the forward, one all-gather of the
+    interior strips -- the stitched frame equals the whole-frame forward (strong scaling; all collectives timed).
 
 Rank 0 prints ONE JSON line.  Besides the driver's fields it carries
   roofline      the dominant kernel (largest share of the forward), timed live with HIP events
@@ -60,6 +63,7 @@ WORKLOADS = {
     "cfg1": (32, 1, 256, 256, "RawFormer-S(FLCA) dim=32, one packed 4x128x128 frame"),
     "cfg3": (48, 8, 1024, 1024, "RawFormer-B(FLCA) dim=48, batch=8 of packed 4x512x512 synthetic Bayer per GPU"),
     "cfg4": (64, 1, 2848, 4256, "RawFormer-L(FLCA) dim=64, one SID Sony full frame, packed 4x1424x2128"),
+    "cfg4x": (64, 1, 2848, 4256, "RawFormer-L(FLCA) dim=64, one SID Sony full frame, packed 4x1424x2128 (exact row shards)"),
     "frame1": (32, 1, 1024, 1024, "RawFormer-S(FLCA) dim=32, ONE packed 4x512x512 frame (test.py:72 batch_size=1)"),
     "cfg5": (32, 4, 1024, 1024, "RawFormer-S(FLCA) dim=32 TRAINING step (forward + L1 loss + backward + gradient all-reduce + AdamW), "
                                 "batch 4 of packed 4x512x512 per GPU"),
@@ -345,8 +349,9 @@ def main():
 
     dim, batch, hm, wm, desc = WORKLOADS[args.workload]
     tiled = args.workload == "cfg4" and world > 1
+    exact = args.workload == "cfg4x" and world > 1
     if args.dry_run:
-        if args.workload == "cfg4":
+        if args.workload in ("cfg4", "cfg4x"):
             hm, wm = 2848 // 4 // 16 * 16, 4256 // 4 // 16 * 16     # a quarter-size frame keeps the rehearsal fast
         else:
             hm, wm = hm // 8, wm // 8
@@ -354,6 +359,14 @@ def main():
 
         def forward(t):   # stand-in of the right shape; NOT the model (no GPU here)
             return t.repeat(1, 3, 1, 1) * 0.5
+
+        class _StandIn:   # rehearses the collectives of RawFormer.forward_window (one sum, one max) around the stand-in forward
+            def forward_window(self, win, y_lo, y_hi, total_rows, group=None):
+                stat = torch.ones(64)
+                dist.all_reduce(stat, group=group)
+                dist.all_reduce(stat, op=dist.ReduceOp.MAX, group=group)
+                return forward(win)
+        model = _StandIn()
     else:
         from bayer_low_light_image_enhancement_amd import RawFormer
         model = RawFormer(dim=dim)
@@ -392,9 +405,16 @@ def main():
         def step():
             with torch.no_grad():
                 return tiling.forward_full_frame_sharded(forward, x, tiles)
+    elif exact:
+        x = torch.from_numpy(synth.bayer_mosaic(10, 1, hm, wm)).to(device)
+        shards = tiling.plan_row_shards(hm // 2, world)
+
+        def step():
+            with torch.no_grad():
+                return tiling.forward_full_frame_exact(model, x)
     else:
         # this rank's images: seeds are disjoint across ranks
-        seed0 = 10 if args.workload == "cfg4" else 2 + rank * batch
+        seed0 = 10 if args.workload in ("cfg4", "cfg4x") else 2 + rank * batch
         x = torch.from_numpy(synth.bayer_mosaic(seed0, batch, hm, wm)).to(device)
 
         def step():
@@ -424,7 +444,7 @@ def main():
         elapsed = float(t.item())
     assert torch.isfinite(out).all()
 
-    mp_per_step = (1 if tiled else world) * batch * hm * wm / 1e6
+    mp_per_step = (1 if (tiled or exact) else world) * batch * hm * wm / 1e6
     model_name = {32: "S", 48: "B", 64: "L"}[dim]
     line = {
         "metric": f"megapixels/sec RawFormer-{model_name} RAW->sRGB" if args.workload != "cfg2" else "megapixels/sec RawFormer-S 512x512 RAW->sRGB",
@@ -435,7 +455,7 @@ def main():
         "warmup": args.warmup,
         "ms_per_step": round(elapsed / args.steps * 1e3, 4),
         "higher_is_better": True,
-        "scaling": "strong" if args.workload == "cfg4" else "weak",
+        "scaling": "strong" if args.workload in ("cfg4", "cfg4x") else "weak",
         "vs_baseline": None,
         "dtype": "f32",     # storage, accumulation and results; the K >= 128 1x1 GEMMs contract three-piece bf16 splits of the f32
                             # operands on the bf16 matrix pipe (same error as the f32 MFMA chain: profiles/r02_ubench_bf16x3.txt)
@@ -443,7 +463,9 @@ def main():
         "config": {"workload": desc, "name": args.workload, "frames_per_gpu": batch, "mosaic": [hm, wm], "packed": [4, hm // 2, wm // 2],
                    "variant": "flca", "weights": "synthetic (seeded, random-init scale)",
                    "parallelism": (f"tile-sharded x{world} (grid {TILE_GRIDS[world][0]}x{TILE_GRIDS[world][1]}, overlap {TILE_OVERLAP}, "
-                                   f"all-gather of tile outputs inside the timed region)") if tiled else f"batch-sharded x{world}",
+                                   f"all-gather of tile outputs inside the timed region)") if tiled else
+                                  (f"exact row shards x{world} (window {shards[0].rows} of {hm // 2} packed rows, statistics all-reduced inside "
+                                   f"the forward, all-gather of the interior strips; all inside the timed region)") if exact else f"batch-sharded x{world}",
                    "device": "cpu (dry run)" if args.dry_run else torch.cuda.get_device_name(local)},
     }
     if args.dry_run:
@@ -457,7 +479,7 @@ def main():
         if trainer is not None:
             line["config"]["final_loss"] = round(float(out), 6)
     if rank == 0 and not args.no_profile and not args.dry_run:
-        prof_step = step if (tiled or args.workload == "cfg5") else (lambda: forward(x))
+        prof_step = step if (tiled or exact or args.workload == "cfg5") else (lambda: forward(x))
         with torch.no_grad():
             recs = profile_pass(prof_step, args.steps)
         total = sum(r["ms"] for r in recs)

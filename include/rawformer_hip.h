@@ -84,6 +84,19 @@ int rf_workspace_bytes(const rf_handle* h, int B, int H, int W, size_t* bytes);
 int rf_forward(rf_handle* h, const float* in, float* out, void* workspace, size_t workspace_bytes,
                int B, int H, int W, int packed_input, void* stream);
 
+/* Exact spatial sharding of ONE frame over several devices (the reference has no counterpart: it
+ * runs whole frames on one device, test.py:116).  Each rank runs rf_forward on a WINDOW of the packed frame: its interior
+ * rows [y_lo, y_hi) (local row indices, multiples of 8) plus enough halo rows for the U-Net's receptive field (76 packed rows)
+ * and the same window height on every rank.  What is global in RawFormer -- the channel attention's Gram / norm statistics
+ * (FrequencyawareLumaChromaAttentionRAWFormer.py:205-221) and FLCA's squeeze-excite pooling (:150-154) -- is accumulated over the
+ * interior rows only and reduced over the ranks through `allreduce(user, buf, n, op, stream)` (n floats, in place, ordered on
+ * `stream`: RCCL all-reduce; op 0 = sum, 1 = max) before it is used; FLCA's luma normaliser (the frame maximum, :59-62) is
+ * the max over the windows; total_rows is the frame's packed height (the pooled mean's denominator).
+ * Interior rows of the output then equal the whole-frame forward up to summation order.  y_lo = y_hi = 0 and a null
+ * callback switch sharding off.  Variants flca and plain. */
+typedef void (*rf_allreduce_fn)(void* user, float* buf, size_t n, int op, void* stream);
+int rf_set_shard(rf_handle* h, int y_lo, int y_hi, int total_rows, rf_allreduce_fn allreduce, void* user);
+
 /* One Conv_Transformer stage of the model, exactly as rf_forward schedules it (branch || TransformerBlock -> cat ->
  * 1x1 -> 3x3 -> LeakyReLU; FrequencyawareLumaChromaAttentionRAWFormer.py:257-278, RawFomer_WFB_FFAB/model.py:393-412,
  * model.py:94-108), including the squeeze-excite fold into channel_reduce.  stage = 1..7 (conv_tran<stage>), at U-Net

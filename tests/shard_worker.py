@@ -1,0 +1,40 @@
+"""Worker of tests/test_exact_shard.py (GPU box): one rank of the exact row-sharded forward.  Every rank also runs the
+whole-frame forward itself and compares; exit code 0 = the stitched frame matches.
+usage: shard_worker.py <rank> <world> <rendezvous file> <packed rows> <packed cols> <dim> <variant> <halo>"""
+import os
+import sys
+
+import torch
+import torch.distributed as dist
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, REPO)
+from bayer_low_light_image_enhancement_amd import RawFormer, synth, tiling  # noqa: E402
+
+
+def main():
+    rank, world, rdv = int(sys.argv[1]), int(sys.argv[2]), sys.argv[3]
+    H, W, dim, variant, halo = int(sys.argv[4]), int(sys.argv[5]), int(sys.argv[6]), sys.argv[7], int(sys.argv[8])
+    backend = os.environ.get("RF_SHARD_BACKEND", "gloo")        # all ranks of this test share ONE GPU: RCCL refuses that
+    dist.init_process_group(backend, init_method=f"file://{rdv}", rank=rank, world_size=world)
+    dev = torch.device("cuda:0")
+    m = RawFormer(dim=dim, variant=variant)
+    synth.fill_state_dict(m.state_dict(), seed=5)
+    m = m.to(dev).eval()
+    g = torch.Generator().manual_seed(11)
+    x = (torch.rand((1, 1, 2 * H, 2 * W), generator=g) * 0.8 + 0.05).to(dev)
+    whole = m(x)
+    got = tiling.forward_full_frame_exact(m, x, halo=halo)
+    err = float((got - whole).abs().max())
+    scale = float(whole.abs().max())
+    tiles = tiling.forward_tiled(m, x, tiling.plan_tiles(2 * H, 2 * W, (world, 1), overlap=2 * halo))     # same context, local statistics
+    err_tiles = float((tiles - whole).abs().max())
+    print(f"rank {rank}: exact-shard max |diff| {err:.3e} (independent tiles with the same context: {err_tiles:.3e}; output scale {scale:.3f})", flush=True)
+    dist.barrier()
+    dist.destroy_process_group()
+    tol = float(os.environ.get("RF_SHARD_TOL", "5e-5"))     # fp32 summation order only (measured 4e-6 .. 8e-6)
+    sys.exit(0 if err <= tol * max(scale, 1.0) else 3)
+
+
+if __name__ == "__main__":
+    main()

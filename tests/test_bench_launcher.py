@@ -43,6 +43,14 @@ def test_cfg4_two_ranks_tile_sharded_with_the_all_gather_in_the_step():
     assert ", 2 tiles" in r.stderr
 
 
+def test_cfg4x_two_ranks_exact_row_shards_with_their_collectives_in_the_step():
+    r = _run("--gpus", "2", "--dry-run", "--workload", "cfg4x", "--steps", "2", "--warmup", "1")
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = _json_line(r.stdout)
+    assert line["n_gpus"] == 2 and line["scaling"] == "strong"
+    assert "exact row shards x2" in line["config"]["parallelism"] and "all-reduced" in line["config"]["parallelism"]
+
+
 def test_cfg5_two_ranks_rehearse_the_bucketed_gradient_all_reduce():
     r = _run("--gpus", "2", "--dry-run", "--workload", "cfg5", "--steps", "2", "--warmup", "1")
     assert r.returncode == 0, r.stderr[-2000:]

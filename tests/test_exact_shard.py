@@ -1,0 +1,57 @@
+"""Exact spatially-sharded whole frame: planner logic on the CPU, and on the GPU box two ranks (two
+processes on the one GPU, gloo all-reduce of the device buffers) against the whole-frame forward."""
+import os
+import subprocess
+import sys
+import tempfile
+
+import pytest
+
+from bayer_low_light_image_enhancement_amd import tiling
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+def test_row_shards_partition_the_frame_with_full_context():
+    for rows, world, halo in ((1424, 8, 80), (1424, 2, 80), (256, 2, 80), (64, 8, 80), (712, 4, 40), (128, 3, 16)):
+        shards = tiling.plan_row_shards(rows, world, halo)
+        assert len(shards) == world and len({s.rows for s in shards}) == 1          # equal windows: equal slab grids
+        pos = 0
+        for s in shards:
+            assert s.dst == pos and s.y_lo % 8 == 0 and s.y_hi % 8 == 0 and s.start % 8 == 0 and s.rows % 8 == 0
+            assert s.start + s.y_lo == s.dst and 0 <= s.start and s.start + s.rows <= rows and s.y_hi <= s.rows
+            # context: `halo` rows beyond the interior, or the frame border
+            assert s.y_lo >= halo or s.start == 0
+            assert s.rows - s.y_hi >= halo or s.start + s.rows == rows
+            pos += s.y_hi - s.y_lo
+        assert pos == rows
+
+
+def test_row_shards_reject_bad_sizes():
+    with pytest.raises(ValueError):
+        tiling.plan_row_shards(100, 2)          # not a multiple of 8
+    with pytest.raises(ValueError):
+        tiling.plan_row_shards(16, 4)           # fewer than 8 rows per shard
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("variant,rows,cols,dim", [("flca", 384, 64, 16), ("plain", 352, 40, 16), ("flca", 512, 128, 32)])
+def test_two_rank_exact_shard_matches_whole_frame(variant, rows, cols, dim):
+    world = 2
+    with tempfile.TemporaryDirectory() as d:
+        rdv = os.path.join(d, "rdv")
+        procs = [subprocess.Popen([sys.executable, os.path.join(HERE, "shard_worker.py"), str(r), str(world), rdv, str(rows), str(cols),
+                                   str(dim), variant, str(tiling.HALO_ROWS)], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+                 for r in range(world)]
+        outs = []
+        for p in procs:
+            try:
+                o, _ = p.communicate(timeout=240)
+            except subprocess.TimeoutExpired:
+                for q in procs:
+                    q.kill()
+                raise
+            outs.append(o)
+    for r, (p, o) in enumerate(zip(procs, outs)):
+        assert p.returncode == 0, f"rank {r} failed:\n{o[-3000:]}"
+        print(o.strip().splitlines()[-1])
