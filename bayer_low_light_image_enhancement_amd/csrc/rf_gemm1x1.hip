@@ -618,7 +618,8 @@ __global__ void __launch_bounds__(256, KB <= 4 ? 2 : 1) conv1x1_b3_ln_kernel(Con
     __shared__ __attribute__((aligned(16))) u32x4 Bl[KB * 768];
     __shared__ __attribute__((aligned(16))) float red[2 * 4 * 64];
     __shared__ float bias_l[1024];
-    constexpr int KPW = KB / 4;               // K blocks each wave loads
+    constexpr int KPW = KB >= 4 ? KB / 4 : 1; // K blocks each wave loads ...
+    constexpr int CPT = KB >= 4 ? 8 : 4;      // ... and channels of a block per lane: K = 64 splits each block over two waves
     constexpr int K = 32 * KB;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int j = lane & 15, kq = lane >> 4;
@@ -632,16 +633,18 @@ __global__ void __launch_bounds__(256, KB <= 4 ? 2 : 1) conv1x1_b3_ln_kernel(Con
     // ---- input tile: wave w holds K blocks [w KPW, (w + 1) KPW), lane (j, kq) channels 8 kq .. 8 kq + 7 of each, 4 pixels.
     // Persistent over pixel tiles: the next tile's loads are issued as soon as this one is split, i.e. behind its whole GEMM
     // (without that the kernel ran at HBM time + MFMA time: all workgroups load, then all multiply).
-    float4 xr[KPW][8];
+    const int kb0 = KB >= 4 ? wave * KPW : wave >> 1;                     // this wave's first K block
+    const int cbase = KB >= 4 ? 8 * kq : 8 * kq + 4 * (wave & 1);         // first of the lane's CPT channels inside a block
+    float4 xr[KPW][CPT];
     auto load_x = [&](int tile) {
         const int q0 = tile * 64 + 4 * j;
         const unsigned ql = (unsigned)(q0 < P ? q0 : 0);
 #pragma unroll
         for (int i = 0; i < KPW; ++i)
 #pragma unroll
-            for (int c = 0; c < 8; ++c) xr[i][c] = ldv(xb, (unsigned)(32 * (wave * KPW + i) + 8 * kq + c) * (unsigned)P + ql);
+            for (int c = 0; c < CPT; ++c) xr[i][c] = ldv(xb, (unsigned)(32 * (kb0 + i) + cbase + c) * (unsigned)P + ql);
     };
-    constexpr bool PREF = KB > 4;          // K = 128 runs two workgroups per CU: no registers left for a tile in flight
+    constexpr bool PREF = KB != 4;         // K = 128 runs two workgroups per CU with 48 B-piece registers: none left for a tile in flight
     if (PREF) load_x(blockIdx.x);
     for (int tile = blockIdx.x; tile < ntile; tile += gridDim.x) {
     if (!PREF) load_x(tile);
@@ -654,7 +657,7 @@ __global__ void __launch_bounds__(256, KB <= 4 ? 2 : 1) conv1x1_b3_ln_kernel(Con
 #pragma unroll
         for (int i = 0; i < KPW; ++i)
 #pragma unroll
-            for (int c = 0; c < 8; ++c) { s[0] += xr[i][c].x; s[1] += xr[i][c].y; s[2] += xr[i][c].z; s[3] += xr[i][c].w; }
+            for (int c = 0; c < CPT; ++c) { s[0] += xr[i][c].x; s[1] += xr[i][c].y; s[2] += xr[i][c].z; s[3] += xr[i][c].w; }
 #pragma unroll
         for (int g = 0; g < 4; ++g) { s[g] += __shfl_xor(s[g], 16); s[g] += __shfl_xor(s[g], 32); }
         if (kq == 0) *reinterpret_cast<float4*>(red + wave * 64 + 4 * j) = make_float4(s[0], s[1], s[2], s[3]);
@@ -667,7 +670,7 @@ __global__ void __launch_bounds__(256, KB <= 4 ? 2 : 1) conv1x1_b3_ln_kernel(Con
 #pragma unroll
         for (int i = 0; i < KPW; ++i)
 #pragma unroll
-            for (int c = 0; c < 8; ++c) {
+            for (int c = 0; c < CPT; ++c) {
                 const float d0 = xr[i][c].x - mean[0], d1 = xr[i][c].y - mean[1], d2 = xr[i][c].z - mean[2], d3 = xr[i][c].w - mean[3];
                 v[0] = fmaf(d0, d0, v[0]); v[1] = fmaf(d1, d1, v[1]); v[2] = fmaf(d2, d2, v[2]); v[3] = fmaf(d3, d3, v[3]);
             }
@@ -685,11 +688,11 @@ __global__ void __launch_bounds__(256, KB <= 4 ? 2 : 1) conv1x1_b3_ln_kernel(Con
     // normalise, split into three bf16 pieces, publish in B-operand order
 #pragma unroll
     for (int i = 0; i < KPW; ++i) {
-        const int kb = wave * KPW + i;
-        u32x4 bp[4][3];
+        const int kb = kb0 + i;
+        unsigned bpd[4][3][CPT / 2];              // [pixel][piece][channel pair]
 #pragma unroll
-        for (int hp = 0; hp < 4; ++hp) {
-            const int k = 32 * kb + 8 * kq + 2 * hp;
+        for (int hp = 0; hp < CPT / 2; ++hp) {
+            const int k = 32 * kb + cbase + 2 * hp;
             const float ga = a.ln_w[k], gb = a.ln_w[k + 1];
             const float ba = a.ln_b ? a.ln_b[k] : 0.f, bb = a.ln_b ? a.ln_b[k + 1] : 0.f;
             const float xa[4] = {xr[i][2 * hp].x, xr[i][2 * hp].y, xr[i][2 * hp].z, xr[i][2 * hp].w};
@@ -701,15 +704,19 @@ __global__ void __launch_bounds__(256, KB <= 4 ? 2 : 1) conv1x1_b3_ln_kernel(Con
                 unsigned a0, a1, a2, b0, b1, b2;
                 b3_split(ya, a0, a1, a2);
                 b3_split(yb, b0, b1, b2);
-                bp[g][0][hp] = b3_pack(a0, b0);
-                bp[g][1][hp] = b3_pack(a1, b1);
-                bp[g][2][hp] = b3_pack(a2, b2);
+                bpd[g][0][hp] = b3_pack(a0, b0);
+                bpd[g][1][hp] = b3_pack(a1, b1);
+                bpd[g][2][hp] = b3_pack(a2, b2);
             }
         }
 #pragma unroll
         for (int g = 0; g < 4; ++g)
 #pragma unroll
-            for (int pc = 0; pc < 3; ++pc) Bl[((kb * 4 + g) * 3 + pc) * 64 + lane] = bp[g][pc];
+            for (int pc = 0; pc < 3; ++pc) {
+                u32x4* dst = &Bl[((kb * 4 + g) * 3 + pc) * 64 + lane];
+                if constexpr (CPT == 8) *dst = (u32x4){bpd[g][pc][0], bpd[g][pc][1], bpd[g][pc][2], bpd[g][pc][3]};
+                else reinterpret_cast<uint2*>(dst)[wave & 1] = make_uint2(bpd[g][pc][0], bpd[g][pc][1]);   // this wave's half of the element
+            }
     }
     __syncthreads();
     if (PREF && tile + (int)gridDim.x < ntile) load_x(tile + gridDim.x);
@@ -724,7 +731,7 @@ __global__ void __launch_bounds__(256, KB <= 4 ? 2 : 1) conv1x1_b3_ln_kernel(Con
             for (int g = 0; g < 4; ++g) acc[t][g] = (f32x4){0.f, 0.f, 0.f, 0.f};
         // A pieces straight from L2, in a ring of RING (K block, tile) steps: a step's three 16-byte loads are issued
         // RING - 1 steps (x 24 MFMAs = 408 cycles each) before their use.
-        constexpr int RING = KB > 4 ? 12 : 5, STEPS = KB * NCO;
+        constexpr int STEPS = KB * NCO, RING = KB > 4 ? 12 : (STEPS < 5 ? STEPS : 5);
         u32x4 A[RING][3];
         auto load_a = [&](int slot, int step) {
             const int kb = step / NCO, t = step - kb * NCO;
@@ -755,7 +762,7 @@ __global__ void __launch_bounds__(256, KB <= 4 ? 2 : 1) conv1x1_b3_ln_kernel(Con
 
 static bool b3_ln_supported(const Conv1x1Args& a, int* nco) {
     const int K = a.C1 + a.C2;
-    if (!(a.ln_w && a.wp3 && a.C2 == 0 && (K == 128 || K == 256) && a.mode == 0 && !a.res && a.Cout % 64 == 0 && a.Cout <= 1024 &&
+    if (!(a.ln_w && a.wp3 && a.C2 == 0 && (K == 64 || K == 128 || K == 256) && a.mode == 0 && !a.res && a.Cout % 64 == 0 && a.Cout <= 1024 &&
           aligned16(a.wp3) && a.wp3_bstride % 4 == 0))
         return false;
     const int tpw = a.Cout / 64;
@@ -855,25 +862,29 @@ int launch_conv1x1(const Conv1x1Args& a, hipStream_t st) {
     const double px = (double)a.B * a.P;
     const double work_flops = 2.0 * K * a.Cout * px, work_bytes = 4.0 * px * (K + a.Cout + (a.res ? a.Cout : 0));
     char key[64];
-    bool use_b3 = a.wp3 && b3_supported(a);
+    bool b3_ok = a.wp3 != nullptr;
 #ifdef RF_DIAG   // diagnostic build only (build.py --diag): force the f32 MFMA kernels
-    if (getenv("RF_NO_B3")) use_b3 = false;
+    if (getenv("RF_NO_B3")) b3_ok = false;
 #endif
+    const bool use_b3 = b3_ok && b3_supported(a);
     if (!vec || (a.res && a.Cout % 16 != 0) || (a.ln_w && K > kStreamLnMaxK)) {
         ProfScope prof(st, "conv1x1_scalar_kernel", work_flops, work_bytes);
         int gx = cdiv(a.P, 256);
         if (gx > 4096) gx = 4096;
         conv1x1_scalar_kernel<<<dim3((unsigned)gx, (unsigned)a.B), 256, 0, st>>>(a);
-    } else if (int nco_ln = 0; use_b3 && b3_ln_supported(a, &nco_ln)) {
+    } else if (int nco_ln = 0; b3_ok && b3_ln_supported(a, &nco_ln)) {
         const int kb = K / 32, tpw = a.Cout / 64;
-        const int slots = (kb == 4 ? 2 : 1) * 256;                // resident workgroups (LDS: 55 KB / 104 KB)
+        const int slots = (kb <= 4 ? 2 : 1) * 256;                // resident workgroups (LDS: 31 / 55 / 104 KB; registers: 2 per CU)
         int gx = slots / a.B;
         gx = gx < 1 ? 1 : gx;
         gx = gx < cdiv(a.P, 64) ? gx : cdiv(a.P, 64);
         dim3 grid((unsigned)gx, (unsigned)a.B, 1);
         snprintf(key, sizeof(key), "conv1x1_b3_ln_kernel<%d, %d>", kb, nco_ln);
         ProfScope prof(st, key, work_flops, work_bytes);
-        if (kb == 4) {
+        if (kb == 2) {
+            if (nco_ln == 3) conv1x1_b3_ln_kernel<2, 3><<<grid, 256, 0, st>>>(a, tpw);
+            else conv1x1_b3_ln_kernel<2, 2><<<grid, 256, 0, st>>>(a, tpw);
+        } else if (kb == 4) {
             if (nco_ln == 3) conv1x1_b3_ln_kernel<4, 3><<<grid, 256, 0, st>>>(a, tpw);
             else conv1x1_b3_ln_kernel<4, 2><<<grid, 256, 0, st>>>(a, tpw);
         } else {
