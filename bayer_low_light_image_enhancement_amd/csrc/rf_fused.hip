@@ -352,15 +352,20 @@ __global__ void __launch_bounds__(256, 2) ffn_fused_kernel(FfnArgs a) {
 
     float4 xh0[NS], xh1[NS];
     GroupGeom g0, g1;
-    if ((int)blockIdx.x < a.ntiles) {
-        const int tx = blockIdx.x % a.tiles_x, ty = blockIdx.x / a.tiles_x;
+    // A workgroup's tiles are CONSECUTIVE and numbered down the columns of the tile grid (ty fastest): successive tiles share two
+    // of their six halo'd rows, which are then still in L2 (strided tiles, numbered along x, re-fetched every halo row from HBM)
+    const int tiles_y = a.ntiles / a.tiles_x;
+    const int per = (a.ntiles + (int)gridDim.x - 1) / (int)gridDim.x;
+    const int t_begin = blockIdx.x * per, t_end = (t_begin + per < a.ntiles) ? t_begin + per : a.ntiles;
+    if (t_begin < t_end) {
+        const int tx = t_begin / tiles_y, ty = t_begin % tiles_y;
         g0 = group_geom(wave, 0, j, ty * TH, tx * TW, h, w);
         g1 = group_geom(wave, 1, j, ty * TH, tx * TW, h, w);
         load_step<C>(xb, P, kq, g0, xh0);
         load_step<C>(xb, P, kq, g1, xh1);
     }
-    for (int tile = blockIdx.x; tile < a.ntiles; tile += gridDim.x) {
-        const int tx = tile % a.tiles_x, ty = tile / a.tiles_x;
+    for (int tile = t_begin; tile < t_end; ++tile) {
+        const int tx = tile / tiles_y, ty = tile % tiles_y;
         const int x0 = tx * TW, y0 = ty * TH;
         STAMP(0);
         // input tile (fetched behind the previous tile's last phase B): LayerNorm in registers
@@ -390,10 +395,10 @@ __global__ void __launch_bounds__(256, 2) ffn_fused_kernel(FfnArgs a) {
             if (part == NPART - 1) {
                 // the input registers are dead now: fetch the next tile, and this tile's residual rows,
                 // behind the last phase B (all loads are issued before this tile's stores)
-                const int tn = tile + gridDim.x;
-                if (tn < a.ntiles) {
-                    g0 = group_geom(wave, 0, j, (tn / a.tiles_x) * TH, (tn % a.tiles_x) * TW, h, w);
-                    g1 = group_geom(wave, 1, j, (tn / a.tiles_x) * TH, (tn % a.tiles_x) * TW, h, w);
+                const int tn = tile + 1;
+                if (tn < t_end) {
+                    g0 = group_geom(wave, 0, j, (tn % tiles_y) * TH, (tn / tiles_y) * TW, h, w);
+                    g1 = group_geom(wave, 1, j, (tn % tiles_y) * TH, (tn / tiles_y) * TW, h, w);
                     load_step<C>(xb, P, kq, g0, xh0);
                     load_step<C>(xb, P, kq, g1, xh1);
                 }
@@ -505,13 +510,16 @@ __global__ void __launch_bounds__(256, 2) attn_front_kernel(AttnFrontArgs a) {
     for (int r = 0; r < NQT; ++r) { gq[r] = (f32x4){0.f, 0.f, 0.f, 0.f}; gnq[r] = gq[r]; gnk[r] = gq[r]; }
     STAMP_DECL
 
-    float warm = 0.f;                                     // see the L2 warm-up below
-    for (int tile = slab; tile < a.ntiles; tile += a.nslab) {
-        const int tx = tile % a.tiles_x, ty = tile / a.tiles_x;
+    // consecutive tiles down the columns of the tile grid (see ffn_fused_kernel)
+    const int tiles_y = a.ntiles / a.tiles_x;
+    const int per = (a.ntiles + a.nslab - 1) / a.nslab;
+    const int t_begin = slab * per, t_end = (t_begin + per < a.ntiles) ? t_begin + per : a.ntiles;
+    for (int tile = t_begin; tile < t_end; ++tile) {
+        const int tx = tile / tiles_y, ty = tile % tiles_y;
         const int x0 = tx * TW, y0 = ty * TH;
         // The input tile is loaded here, not a tile ahead: the b3 pieces (96 registers) already fill the budget that the
         // f32 kernel of round 1 spent on the next tile's raw values.  The loads are issued before the barrier so that their
-        // latency overlaps the wait, and the lines were pulled into L2 a tile ago (below).
+        // latency overlaps the wait (throw-away loads warming L2 for the next tile were measured: 3 % slower).
         const GroupGeom g0 = group_geom(wave, 0, j, y0, x0, h, w), g1 = group_geom(wave, 1, j, y0, x0, h, w);
         float4 xh0[NS], xh1[NS];
         load_step_b3<C>(xb, P, kq, g0, xh0);
@@ -564,22 +572,6 @@ __global__ void __launch_bounds__(256, 2) attn_front_kernel(AttnFrontArgs a) {
             phase_a_step_b3<C, NT3>(bp0, w_l + lane, t0, t0 + 1, bq_l + 2 * C + vp * PART, bq_l + 2 * C + vp * PART + 16, mid, PSV, kq, g0);
             phase_a_step_b3<C, NT3>(bp1, w_l + lane, t0, t0 + 1, bq_l + 2 * C + vp * PART, bq_l + 2 * C + vp * PART + 16, mid, PSV, kq, g1);
             STAMP(2);
-#ifndef RF_NO_WARM
-            if (vp == NVP - 1) {
-                // L2 warm-up for the next tile: its 6 rows x 32 channels x (72 px = at most 4 lines of 128 bytes) = 768 lines,
-                // three throw-away 4-byte loads per thread, consumed (added into `warm`) only after the next tile's own loads.
-                const int tn = tile + a.nslab;
-                if (tn < a.ntiles) {
-                    const int nx0 = (tn % a.tiles_x) * TW, ny0 = (tn / a.tiles_x) * TH;
-#pragma unroll
-                    for (int i = 0; i < 3; ++i) {
-                        const int idx = tid + 256 * i, ln = idx & 3, row = (idx >> 2) % HR, ch = idx / (4 * HR);
-                        const int yy = min(max(ny0 - 1 + row, 0), h - 1), xx = min(max(nx0 - 4 + 32 * ln, 0), w - 1);
-                        warm += xb[(size_t)ch * P + (size_t)yy * w + xx];
-                    }
-                }
-            }
-#endif
             lds_barrier();
             STAMP(0);
             const int xo = x0 + 4 * j;
@@ -618,7 +610,6 @@ __global__ void __launch_bounds__(256, 2) attn_front_kernel(AttnFrontArgs a) {
             dst[i] = ((red[i] + red[16 * ROWW + i]) + red[2 * 16 * ROWW + i]) + red[3 * 16 * ROWW + i];
         __syncthreads();
     }
-    if (a.B < 0) a.partial[0] = warm;                      // never true: keeps the warm-up loads alive
 }
 
 bool fused_attn_supported(int C, int heads, int h, int w) {
@@ -700,6 +691,8 @@ __global__ void __launch_bounds__(256, 2) attn_mid_kernel(AttnMidArgs a) {
         const int pl = e / (HR * (HC / 4)), rem = e % (HR * (HC / 4));
         pk[i] = e < NF4 ? (pl << 16) | ((rem / (HC / 4)) << 8) | (rem % (HC / 4)) : -1;
     }
+    // (tiles stay strided and numbered along x here: the consecutive column order of ffn_fused_kernel / attn_front_kernel was
+    // measured 10 % slower at C = 128 and neutral at C = 64)
     unsigned voff[FPT];       // current tile: byte offset of (row, group) inside a plane, OOB outside the image
     auto plan_tile = [&](int tile) {
         const int y0 = (tile / a.tiles_x) * TH, x0 = (tile % a.tiles_x) * TW;
@@ -798,13 +791,12 @@ __global__ void __launch_bounds__(256, 2) attn_mid_kernel(AttnMidArgs a) {
             // (the next step's data is still in registers: mid is free between the two barriers)
             __syncthreads();
             float* red = mid;
+            for (int i = tid; i < 64 * 48; i += 256) red[(i / 48) * ROWW + 16 + i % 48] = 0.f;      // zero key tiles: see attn_front_kernel
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
                 const int row = 4 * kq + q;
                 float* rr = red + (wave * 16 + row) * ROWW;
                 rr[j] = gq[q];
-#pragma unroll
-                for (int c = 16; c < 64; c += 16) rr[c + j] = 0.f;
                 if (row == j) { rr[64] = gnq[q]; rr[65] = gnk[q]; }
             }
             __syncthreads();
