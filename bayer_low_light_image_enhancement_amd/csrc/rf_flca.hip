@@ -6,6 +6,7 @@
 //                   + per-block channel sums for the squeeze-excite pooling
 //   flca_se_fold  : SE MLP, then folds the per-image channel gate into the following
 //                   channel_reduce 1x1:  W_cr [x*ch ; trans] = [W_a diag(ch) | W_b] [x ; trans]
+#include <type_traits>
 #include "rf_common.h"
 
 namespace rf {
@@ -168,11 +169,12 @@ int launch_guidance_level(const float* scratch, float* guide, int B, int H, int 
 // The 36 weights of a channel are wave-uniform (scalar loads).  Per-block channel sums feed the
 // squeeze-excite pooling without atomics.
 static constexpr int kFlcaCG = 32;   // channels per workgroup: (pixel block, channel group, image) grid keeps small levels parallel
-int flca_nblk(int h, int w) { return (w % 4 == 0) ? cdiv(h * w, 1024) : cdiv(h * w, 256); }
+int flca_nblk(int h, int w) { return (w % 4 == 0) ? cdiv(h * w, 1024) : (w % 2 == 0) ? cdiv(h * w, 512) : cdiv(h * w, 256); }
 
 __device__ __forceinline__ float fast_sigmoid(float x) { return __builtin_amdgcn_rcpf(1.0f + __expf(-x)); }
 __device__ __forceinline__ float fast_tanh(float x) { return 1.0f - 2.0f * __builtin_amdgcn_rcpf(1.0f + __expf(2.0f * x)); }
 
+template <int PX>   // pixels of a row per lane: 4 (w % 4 == 0) or 2 (w % 4 == 2, e.g. level 3 of a 2848 x 4256 frame: w = 266)
 __global__ void __launch_bounds__(256) flca_spatial_vec_kernel(FlcaSpatialArgs a, const float* __restrict__ w_low,
                                                                const float* __restrict__ w_high, const float* __restrict__ w_chr,
                                                                const float* __restrict__ feat, float* __restrict__ xs) {
@@ -180,11 +182,11 @@ __global__ void __launch_bounds__(256) flca_spatial_vec_kernel(FlcaSpatialArgs a
     const size_t b = blockIdx.z;
     const int h = a.h, w = a.w, P = h * w, C = a.C;
     const int c_lo = blockIdx.y * kFlcaCG, c_hi = (c_lo + kFlcaCG < C) ? c_lo + kFlcaCG : C;   // this workgroup's channels
-    const int p = (blk * 256 + threadIdx.x) * 4;
+    const int p = (blk * 256 + threadIdx.x) * PX;
     const bool live = p < P;
     const int y = live ? p / w : 0, x = live ? p - (p / w) * w : 0;
     const bool counted = y >= a.ylo && y < (a.yhi > 0 ? a.yhi : h);      // rows of the squeeze-excite pooling
-    float nb[4][3][6];
+    float nb[4][3][PX + 2];
     const float* gb = a.guide + b * 4 * (size_t)P;
 #pragma unroll
     for (int pl = 0; pl < 4; ++pl)
@@ -193,46 +195,62 @@ __global__ void __launch_bounds__(256) flca_spatial_vec_kernel(FlcaSpatialArgs a
             const int yy = y + dy - 1;
             const bool rok = live && yy >= 0 && yy < h;
             const float* row = gb + (size_t)pl * P + (size_t)(rok ? yy : 0) * w;
-            const float4 m = *reinterpret_cast<const float4*>(row + x);
-            const float l = row[x > 0 ? x - 1 : 0], r = row[x + 4 < w ? x + 4 : 0];
+            float m[PX];
+            if constexpr (PX == 4) {
+                const float4 t = *reinterpret_cast<const float4*>(row + x);
+                m[0] = t.x; m[1] = t.y; m[2] = t.z; m[3] = t.w;
+            } else {
+                const float2 t = *reinterpret_cast<const float2*>(row + x);
+                m[0] = t.x; m[1] = t.y;
+            }
+            const float l = row[x > 0 ? x - 1 : 0], r = row[x + PX < w ? x + PX : 0];
             nb[pl][dy][0] = (rok && x > 0) ? l : 0.f;
-            nb[pl][dy][1] = rok ? m.x : 0.f; nb[pl][dy][2] = rok ? m.y : 0.f;
-            nb[pl][dy][3] = rok ? m.z : 0.f; nb[pl][dy][4] = rok ? m.w : 0.f;
-            nb[pl][dy][5] = (rok && x + 4 < w) ? r : 0.f;
+#pragma unroll
+            for (int q = 0; q < PX; ++q) nb[pl][dy][1 + q] = rok ? m[q] : 0.f;
+            nb[pl][dy][PX + 1] = (rok && x + PX < w) ? r : 0.f;
         }
     const float al = *a.alpha, be = *a.beta, ga = *a.gamma;
     __shared__ float red[kFlcaCG][4];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const float* fb = feat + b * (size_t)C * P + (live ? p : 0);
     float* xb = xs + b * (size_t)C * P + p;
-    float4 fcur = *reinterpret_cast<const float4*>(fb + (size_t)c_lo * P);
+    typedef typename std::conditional<PX == 4, float4, float2>::type vecT;
+    vecT fcur = *reinterpret_cast<const vecT*>(fb + (size_t)c_lo * P);
     for (int c = c_lo; c < c_hi; ++c) {
-        const float4 fnext = *reinterpret_cast<const float4*>(fb + (size_t)(c + 1 < c_hi ? c + 1 : c) * P);
+        const vecT fnext = *reinterpret_cast<const vecT*>(fb + (size_t)(c + 1 < c_hi ? c + 1 : c) * P);
         const float* wl = w_low + c * 9;
         const float* wh = w_high + c * 9;
         const float* wc = w_chr + c * 18;
-        float sl[4] = {0.f, 0.f, 0.f, 0.f}, sh[4] = {0.f, 0.f, 0.f, 0.f}, sc[4] = {0.f, 0.f, 0.f, 0.f};
+        float sl[PX], sh[PX], sc[PX];
+#pragma unroll
+        for (int q = 0; q < PX; ++q) { sl[q] = 0.f; sh[q] = 0.f; sc[q] = 0.f; }
 #pragma unroll
         for (int dy = 0; dy < 3; ++dy)
 #pragma unroll
             for (int dx = 0; dx < 3; ++dx) {
                 const float k0 = wl[dy * 3 + dx], k1 = wh[dy * 3 + dx], k2 = wc[dy * 3 + dx], k3 = wc[9 + dy * 3 + dx];
 #pragma unroll
-                for (int q = 0; q < 4; ++q) {
+                for (int q = 0; q < PX; ++q) {
                     sl[q] = fmaf(k0, nb[0][dy][q + dx], sl[q]);
                     sh[q] = fmaf(k1, nb[1][dy][q + dx], sh[q]);
                     sc[q] = fmaf(k3, nb[3][dy][q + dx], fmaf(k2, nb[2][dy][q + dx], sc[q]));
                 }
             }
-        float v[4];
-        const float fv[4] = {fcur.x, fcur.y, fcur.z, fcur.w};
+        float v[PX], fv[PX];
+        if constexpr (PX == 4) { fv[0] = fcur.x; fv[1] = fcur.y; fv[2] = fcur.z; fv[3] = fcur.w; }
+        else { fv[0] = fcur.x; fv[1] = fcur.y; }
 #pragma unroll
-        for (int q = 0; q < 4; ++q)
+        for (int q = 0; q < PX; ++q)
             v[q] = fv[q] * (1.0f + al * fast_sigmoid(sl[q]) + be * fast_tanh(sh[q]) + ga * fast_sigmoid(sc[q]));
         float s = 0.f;
         if (live) {
-            *reinterpret_cast<float4*>(xb + (size_t)c * P) = make_float4(v[0], v[1], v[2], v[3]);
-            if (counted) s = (v[0] + v[1]) + (v[2] + v[3]);
+            if constexpr (PX == 4) {
+                *reinterpret_cast<float4*>(xb + (size_t)c * P) = make_float4(v[0], v[1], v[2], v[3]);
+                if (counted) s = (v[0] + v[1]) + (v[2] + v[3]);
+            } else {
+                *reinterpret_cast<float2*>(xb + (size_t)c * P) = make_float2(v[0], v[1]);
+                if (counted) s = v[0] + v[1];
+            }
         }
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
@@ -299,11 +317,13 @@ int launch_flca_spatial(const FlcaSpatialArgs& a, hipStream_t st) {
     RF_CHECK_ARG(a.C <= 512 && a.B <= 65535, "flca: C=%d > 512 not supported", a.C);
     RF_CHECK_ARG(a.nblk == flca_nblk(a.h, a.w), "flca: partial-sum block count mismatch");
     const double el = (double)a.B * a.C * a.h * a.w;
-    const bool vec = (a.w % 4 == 0) && aligned16(a.feat) && aligned16(a.xs) && aligned16(a.guide);
-    RF_CHECK_ARG(vec || a.w % 4 != 0, "flca: feature / guidance buffers must be 16-byte aligned");
-    ProfScope prof(st, vec ? "flca_spatial_vec_kernel" : "flca_spatial_kernel", 80.0 * el, 8.0 * el);
-    if (vec)
-        flca_spatial_vec_kernel<<<dim3((unsigned)a.nblk, (unsigned)cdiv(a.C, kFlcaCG), (unsigned)a.B), 256, 0, st>>>(a, a.w_low, a.w_high, a.w_chr, a.feat, a.xs);
+    const bool vec = (a.w % 2 == 0) && aligned16(a.feat) && aligned16(a.xs) && aligned16(a.guide) && ((size_t)a.h * a.w) % 2 == 0;
+    RF_CHECK_ARG(vec || a.w % 2 != 0, "flca: feature / guidance buffers must be 16-byte aligned");
+    ProfScope prof(st, vec ? (a.w % 4 == 0 ? "flca_spatial_vec_kernel" : "flca_spatial_vec_kernel<2>") : "flca_spatial_kernel", 80.0 * el, 8.0 * el);
+    if (vec && a.w % 4 == 0)
+        flca_spatial_vec_kernel<4><<<dim3((unsigned)a.nblk, (unsigned)cdiv(a.C, kFlcaCG), (unsigned)a.B), 256, 0, st>>>(a, a.w_low, a.w_high, a.w_chr, a.feat, a.xs);
+    else if (vec)
+        flca_spatial_vec_kernel<2><<<dim3((unsigned)a.nblk, (unsigned)cdiv(a.C, kFlcaCG), (unsigned)a.B), 256, 0, st>>>(a, a.w_low, a.w_high, a.w_chr, a.feat, a.xs);
     else
         flca_spatial_kernel<<<dim3((unsigned)a.nblk, (unsigned)a.B), 256, 0, st>>>(a);
     return check_launch("flca_spatial");

@@ -362,6 +362,14 @@ __global__ void __launch_bounds__(kBlock) dwconv3x3_kernel(DwConvArgs a) {
                 v[1] = rok ? t.x : 0.f; v[2] = rok ? t.y : 0.f; v[3] = rok ? t.z : 0.f; v[4] = rok ? t.w : 0.f;
                 v[0] = (rok && x0 > 0) ? l : 0.f;
                 v[5] = (rok && x0 + 4 < w) ? r : 0.f;
+            } else if constexpr (VEC == 2) {      // even widths that are not multiples of 4 (w = 266 at level 3 of a 2848 x 4256 frame)
+                const bool rok = y >= 0 && y < h;
+                const float* row = x + (size_t)(rok ? y : 0) * w;
+                const float2 t = *reinterpret_cast<const float2*>(row + x0);
+                const float l = row[x0 > 0 ? x0 - 1 : 0], r = row[x0 + 2 < w ? x0 + 2 : x0];
+                v[1] = rok ? t.x : 0.f; v[2] = rok ? t.y : 0.f;
+                v[0] = (rok && x0 > 0) ? l : 0.f;
+                v[3] = (rok && x0 + 2 < w) ? r : 0.f;
             } else if (y >= 0 && y < h) {
                 const float* row = x + (size_t)y * w;
                 v[1] = row[x0];
@@ -391,6 +399,8 @@ __global__ void __launch_bounds__(kBlock) dwconv3x3_kernel(DwConvArgs a) {
                 }
                 if constexpr (VEC == 4)
                     *reinterpret_cast<float4*>(o + (size_t)y * w + x0) = make_float4(acc[r][0], acc[r][1], acc[r][2], acc[r][3]);
+                else if constexpr (VEC == 2)
+                    *reinterpret_cast<float2*>(o + (size_t)y * w + x0) = make_float2(acc[r][0], acc[r][1]);
                 else
                     o[(size_t)y * w + x0] = acc[r][0];
             }
@@ -402,13 +412,19 @@ int launch_dwconv3x3(const DwConvArgs& a, hipStream_t st) {
     const bool vec = (a.w_ & 3) == 0 && aligned16(a.x) && aligned16(a.out) && (a.x_bstride & 3) == 0 && (a.out_bstride & 3) == 0;
     const double el = (double)a.B * a.C * a.h * a.w_;
     const bool tall = vec && a.h % 8 == 0;   // 8 output rows per thread: 10 row loads per 8 rows instead of 6 per 4
-    ProfScope prof(st, vec ? (tall ? "dwconv3x3_kernel<4, 8>" : "dwconv3x3_kernel<4, 4>") : "dwconv3x3_kernel<1, 4>", 18.0 * el, 8.0 * el);
+    const bool vec2 = !vec && (a.w_ & 1) == 0 && aligned16(a.x) && aligned16(a.out) && (a.x_bstride & 1) == 0 && (a.out_bstride & 1) == 0 &&
+                      (((size_t)a.h * a.w_) & 1) == 0;
+    ProfScope prof(st, vec ? (tall ? "dwconv3x3_kernel<4, 8>" : "dwconv3x3_kernel<4, 4>") : vec2 ? "dwconv3x3_kernel<2, 8>" : "dwconv3x3_kernel<1, 4>",
+                   18.0 * el, 8.0 * el);
     if (tall) {
         const size_t items = (size_t)a.B * a.C * (a.h / 8) * (a.w_ / 4);
         dwconv3x3_kernel<4, 8><<<grid_for(items), kBlock, 0, st>>>(a);
     } else if (vec) {
         const size_t items = (size_t)a.B * a.C * cdiv(a.h, 4) * (a.w_ / 4);
         dwconv3x3_kernel<4, 4><<<grid_for(items), kBlock, 0, st>>>(a);
+    } else if (vec2) {
+        const size_t items = (size_t)a.B * a.C * cdiv(a.h, 8) * (a.w_ / 2);
+        dwconv3x3_kernel<2, 8><<<grid_for(items), kBlock, 0, st>>>(a);
     } else {
         const size_t items = (size_t)a.B * a.C * cdiv(a.h, 4) * a.w_;
         dwconv3x3_kernel<1, 4><<<grid_for(items), kBlock, 0, st>>>(a);

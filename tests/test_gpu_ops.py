@@ -253,6 +253,16 @@ def test_flca_golden(ops, g, device):
         close(out, g[f"flca_c{c}"])
 
 
+@pytest.mark.parametrize("c,hw", [(32, (10, 266)), (16, (7, 34))])
+def test_flca_even_width_not_multiple_of_four(ops, device, c, hw):
+    """w % 4 == 2 (level 3 of a 2848 x 4256 frame is 266 wide): the two-pixel vector path of the spatial gate and its pooled sums."""
+    x4 = rnd("x.packed.w2", (1, 4, 2 * hw[0], 2 * hw[1]), 0, 1)
+    feat = rnd(f"x.flca.w2.{c}", (1, c) + hw)
+    p = params(cases.flca_spec(c))
+    ref = R.flca(feat, *R.bayer_luma_chroma(x4), p, "")
+    close(ops.flca(feat.to(device), x4.to(device), dev(p, device)), ref, 2e-5)
+
+
 @pytest.mark.gpu
 def test_upsample_cat_reduce_matches_two_step_reference(device):
     """Decoder step on composed weights vs ConvTranspose2d -> cat -> Conv2d (model.py:494-503) in torch fp32 on the CPU."""
