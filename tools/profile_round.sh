@@ -20,7 +20,9 @@ python3 tools/mfma_util.py $out/sq $out/mfma_util_a.json > $out/mfma_util.txt 2>
 python3 tools/mfma_util.py $out/sq2 $out/mfma_util_b.json >> $out/mfma_util.txt 2>&1
 # 4. bench lines (un-profiled) for every workload, the default one with the CPU baseline
 python3 bench.py > $out/bench_cfg2.json 2> $out/bench_cfg2.err
-for w in cfg1 cfg3 cfg4 frame1; do python3 bench.py --workload $w --no-cpu-baseline > $out/bench_$w.json 2> $out/bench_$w.err; done
+for w in cfg1 cfg3 cfg4 frame1 cfg5; do python3 bench.py --workload $w --no-cpu-baseline > $out/bench_$w.json 2> $out/bench_$w.err; done
+# 4b. kernel-trace statistics of the training step
+rocprofv3 --kernel-trace --stats -d $out/stats5 -o s --output-format csv -- python3 bench.py --workload cfg5 --no-cpu-baseline --steps 5 --warmup 2 > $out/bench_cfg5_profiled.json 2> $out/stats5.log
 # 5. microbenchmarks
 tools/ubench/mfma_valu > $out/ubench_mfma_valu.txt 2>&1
 tools/ubench/bf16x3 > $out/ubench_bf16x3.txt 2>&1
