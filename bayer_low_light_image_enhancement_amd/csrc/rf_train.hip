@@ -111,11 +111,32 @@ __global__ void __launch_bounds__(256) gram2_kernel(Gram2Args g) {
 }
 
 // out[e] (+)= sum over slabs of partial[slab][e], in slab order
+// Sums over slabs: a block handles 32 elements x 8 slab parts (thread = (element e0 + t % 32, part t / 32) adds slabs part,
+// part + 8, ... in order; the 8 part sums are combined in a fixed order through LDS), so that a reduction over a few hundred
+// slabs of a small matrix is 8 x shorter per thread and fills more than a handful of workgroups.  Deterministic.
+constexpr int kRedElems = 32, kRedParts = 8;
+__device__ __forceinline__ float slab_sum(const float* __restrict__ base, size_t stride, int nslab, bool ok, float (&lds)[kRedParts][kRedElems]) {
+    const int el = threadIdx.x % kRedElems, part = threadIdx.x / kRedElems;
+    float s = 0.f;
+    if (ok)
+        for (int k = part; k < nslab; k += kRedParts) s += base[(size_t)k * stride];
+    lds[part][el] = s;
+    __syncthreads();
+    float t = 0.f;
+    if (part == 0) {
+#pragma unroll
+        for (int q = 0; q < kRedParts; ++q) t += lds[q][el];
+    }
+    __syncthreads();
+    return t;       // valid in part 0
+}
+
 __global__ void __launch_bounds__(256) reduce_partials_kernel(const float* __restrict__ partial, float* __restrict__ out, int nslab, size_t n, int accumulate) {
-    for (size_t e = blockIdx.x * 256ull + threadIdx.x; e < n; e += (size_t)gridDim.x * 256) {
-        float s = 0.f;
-        for (int k = 0; k < nslab; ++k) s += partial[(size_t)k * n + e];
-        out[e] = accumulate ? out[e] + s : s;
+    __shared__ float lds[kRedParts][kRedElems];
+    for (size_t e0 = (size_t)blockIdx.x * kRedElems; e0 < n; e0 += (size_t)gridDim.x * kRedElems) {
+        const size_t e = e0 + threadIdx.x % kRedElems;
+        const float s = slab_sum(partial + (e < n ? e : 0), n, nslab, e < n, lds);
+        if (threadIdx.x < kRedElems && e < n) out[e] = accumulate ? out[e] + s : s;
     }
 }
 
@@ -123,26 +144,33 @@ __global__ void __launch_bounds__(256) reduce_partials_kernel(const float* __res
 // group = image when the result is wanted per image, else one group over all slabs)
 __global__ void __launch_bounds__(256) reduce_gram2_kernel(const float* __restrict__ partial, float* __restrict__ out, int nslab_per_group, int ntap,
                                                            int Ca, int Cb, int ld, size_t out_gstride, int accumulate) {
+    __shared__ float lds[kRedParts][kRedElems];
     const size_t n = (size_t)ntap * Ca * Cb;
     const int grp = blockIdx.y;
     const float* pg = partial + (size_t)grp * nslab_per_group * n;
-    for (size_t e = blockIdx.x * 256ull + threadIdx.x; e < n; e += (size_t)gridDim.x * 256) {
-        float s = 0.f;
-        for (int k = 0; k < nslab_per_group; ++k) s += pg[(size_t)k * n + e];
-        const int j = (int)(e % Cb), i = (int)((e / Cb) % Ca), tap = (int)(e / ((size_t)Ca * Cb));
-        float* o = out + (size_t)grp * out_gstride + ((size_t)i * ld + j) * ntap + tap;
-        *o = accumulate ? *o + s : s;
+    for (size_t e0 = (size_t)blockIdx.x * kRedElems; e0 < n; e0 += (size_t)gridDim.x * kRedElems) {
+        const size_t e = e0 + threadIdx.x % kRedElems;
+        const float s = slab_sum(pg + (e < n ? e : 0), n, nslab_per_group, e < n, lds);
+        if (threadIdx.x < kRedElems && e < n) {
+            const int j = (int)(e % Cb), i = (int)((e / Cb) % Ca), tap = (int)(e / ((size_t)Ca * Cb));
+            float* o = out + (size_t)grp * out_gstride + ((size_t)i * ld + j) * ntap + tap;
+            *o = accumulate ? *o + s : s;
+        }
     }
 }
 
 // depthwise partials [(img, blk)][C][10] -> dw[c][9] and db[c]
 __global__ void __launch_bounds__(256) reduce_dw_kernel(const float* __restrict__ partial, float* __restrict__ dw, float* __restrict__ db, int nslab, int C, int accumulate) {
-    for (int e = blockIdx.x * 256 + threadIdx.x; e < C * 10; e += gridDim.x * 256) {
-        float s = 0.f;
-        for (int k = 0; k < nslab; ++k) s += partial[(size_t)k * C * 10 + e];
-        const int c = e / 10, t = e % 10;
-        float* o = t < 9 ? dw + c * 9 + t : (db ? db + c : nullptr);
-        if (o) *o = accumulate ? *o + s : s;
+    __shared__ float lds[kRedParts][kRedElems];
+    const int n = C * 10;
+    for (int e0 = blockIdx.x * kRedElems; e0 < n; e0 += gridDim.x * kRedElems) {
+        const int e = e0 + threadIdx.x % kRedElems;
+        const float s = slab_sum(partial + (e < n ? e : 0), (size_t)n, nslab, e < n, lds);
+        if (threadIdx.x < kRedElems && e < n) {
+            const int c = e / 10, t = e % 10;
+            float* o = t < 9 ? dw + c * 9 + t : (db ? db + c : nullptr);
+            if (o) *o = accumulate ? *o + s : s;
+        }
     }
 }
 
@@ -223,26 +251,68 @@ __global__ void __launch_bounds__(256) ln_wgrad_kernel(const float* __restrict__
 // ---------------------------------------------------------------------------------------------
 // depthwise 3x3: weight and bias gradients.  partial[((img * nblk + blk) * C + c) * 10 + {9 taps, bias}]
 // ---------------------------------------------------------------------------------------------
+// VEC = 4 (w % 4 == 0): a lane owns a 4-pixel x 8-row strip like dwconv3x3_kernel<4, 8> -- 8 rows of dy and 10 rows of x
+// (16-byte loads + the two edge taps, all unconditional on clamped addresses) feed the nine tap sums; VEC = 1: one pixel per
+// lane with predicated neighbour loads (odd widths).
+template <int VEC>
 __global__ void __launch_bounds__(256) dw_wgrad_kernel(const float* __restrict__ x, const float* __restrict__ dy, float* __restrict__ partial,
                                                        int C, int h, int w, int nblk) {
     const int blk = blockIdx.x, c = blockIdx.y, img = blockIdx.z;
     const int P = h * w;
     const float* xr = x + ((size_t)img * C + c) * P;
     const float* dr = dy + ((size_t)img * C + c) * P;
-    const int per = (P + nblk - 1) / nblk;
-    const int lo = blk * per, hi = (lo + per < P) ? lo + per : P;
     float s[10];
 #pragma unroll
     for (int k = 0; k < 10; ++k) s[k] = 0.f;
-    for (int p = lo + threadIdx.x; p < hi; p += 256) {
-        const int y = p / w, xx = p - y * w;
-        const float d = dr[p];
+    if constexpr (VEC == 4) {
+        constexpr int ROWS = 8;
+        const int wv = w / 4, hr = (h + ROWS - 1) / ROWS, items = wv * hr;
+        const int per = (items + nblk - 1) / nblk;
+        const int lo = blk * per, hi = (lo + per < items) ? lo + per : items;
+        for (int it = lo + threadIdx.x; it < hi; it += 256) {
+            const int x0 = (it % wv) * 4, y0 = (it / wv) * ROWS;
+            float d[ROWS][4];
 #pragma unroll
-        for (int k = 0; k < 9; ++k) {
-            const int yy = y + k / 3 - 1, xc = xx + k % 3 - 1;
-            if (yy >= 0 && yy < h && xc >= 0 && xc < w) s[k] = fmaf(d, xr[(size_t)yy * w + xc], s[k]);
+            for (int r = 0; r < ROWS; ++r) {
+                const bool ok = y0 + r < h;
+                const float4 t = *reinterpret_cast<const float4*>(dr + (size_t)(ok ? y0 + r : 0) * w + x0);
+                d[r][0] = ok ? t.x : 0.f; d[r][1] = ok ? t.y : 0.f; d[r][2] = ok ? t.z : 0.f; d[r][3] = ok ? t.w : 0.f;
+                s[9] += (d[r][0] + d[r][1]) + (d[r][2] + d[r][3]);
+            }
+#pragma unroll
+            for (int rr = 0; rr < ROWS + 2; ++rr) {
+                const int y = y0 + rr - 1;
+                const bool rok = y >= 0 && y < h;
+                const float* row = xr + (size_t)(rok ? y : 0) * w;
+                const float4 t = *reinterpret_cast<const float4*>(row + x0);
+                const float l = row[x0 > 0 ? x0 - 1 : 0], rg = row[x0 + 4 < w ? x0 + 4 : x0];
+                const float v[6] = {(rok && x0 > 0) ? l : 0.f, rok ? t.x : 0.f, rok ? t.y : 0.f, rok ? t.z : 0.f, rok ? t.w : 0.f,
+                                    (rok && x0 + 4 < w) ? rg : 0.f};
+#pragma unroll
+                for (int r = 0; r < ROWS; ++r) {
+                    const int ky = rr - r;          // input row rr is tap row ky of output row r
+                    if (ky >= 0 && ky < 3) {
+#pragma unroll
+                        for (int kx = 0; kx < 3; ++kx)
+#pragma unroll
+                            for (int q = 0; q < 4; ++q) s[ky * 3 + kx] = fmaf(d[r][q], v[q + kx], s[ky * 3 + kx]);
+                    }
+                }
+            }
         }
-        s[9] += d;
+    } else {
+        const int per = (P + nblk - 1) / nblk;
+        const int lo = blk * per, hi = (lo + per < P) ? lo + per : P;
+        for (int p = lo + threadIdx.x; p < hi; p += 256) {
+            const int y = p / w, xx = p - y * w;
+            const float d = dr[p];
+#pragma unroll
+            for (int k = 0; k < 9; ++k) {
+                const int yy = y + k / 3 - 1, xc = xx + k % 3 - 1;
+                if (yy >= 0 && yy < h && xc >= 0 && xc < w) s[k] = fmaf(d, xr[(size_t)yy * w + xc], s[k]);
+            }
+            s[9] += d;
+        }
     }
     __shared__ float red[10][4];
 #pragma unroll
@@ -319,6 +389,11 @@ __global__ void __launch_bounds__(256) adam_kernel(float* __restrict__ p, const 
     }
 }
 
+int red_grid(size_t n) {          // blocks of the slab reducers: 32 elements each
+    size_t g = (n + kRedElems - 1) / kRedElems;
+    return (int)(g > 2048 ? 2048 : g < 1 ? 1 : g);
+}
+
 int grid1d(size_t n, int cap = 4096) {
     int g = (int)((n + 255) / 256);
     if (g > cap) g = cap;
@@ -358,14 +433,14 @@ int launch_gram2(const float* a, int64_t a_bstride, int Ca, const float* b, int6
     if (ntap == 1) gram2_kernel<1><<<dim3((unsigned)nslab, (unsigned)cdiv(Ca, 16), (unsigned)cdiv(Cb, 64)), 256, 0, st>>>(g);
     else gram2_kernel<9><<<dim3((unsigned)nslab, (unsigned)cdiv(Ca, 16), (unsigned)cdiv(Cb, 16)), 256, 0, st>>>(g);
     const size_t n = (size_t)ntap * Ca * Cb;
-    reduce_gram2_kernel<<<dim3((unsigned)grid1d(n, 256), per_image ? (unsigned)B : 1u), 256, 0, st>>>(
+    reduce_gram2_kernel<<<dim3((unsigned)red_grid(n), per_image ? (unsigned)B : 1u), 256, 0, st>>>(
         partial, out, per_image ? g.slabs_per_image : nslab, ntap, Ca, Cb, ld, out_istride, accumulate);
     return check_launch("gram2");
 }
 
 // out[e] (+)= sum over rows of partial[row][e]
 int launch_reduce_rows(const float* partial, float* out, int nrows, size_t n, int accumulate, hipStream_t st) {
-    reduce_partials_kernel<<<grid1d(n), 256, 0, st>>>(partial, out, nrows, n, accumulate);
+    reduce_partials_kernel<<<red_grid(n), 256, 0, st>>>(partial, out, nrows, n, accumulate);
     return check_launch("reduce_rows");
 }
 
@@ -374,7 +449,7 @@ int chan_sum_nblk(int P) { int n = P / 4096; return n < 1 ? 1 : n > 64 ? 64 : n;
 int launch_chan_sum(const float* x, int64_t bstride, float* out, float* partial, int B, int C, int P, int accumulate, hipStream_t st) {
     const int nblk = chan_sum_nblk(P);
     chan_sum_kernel<<<dim3((unsigned)nblk, (unsigned)C, (unsigned)B), 256, 0, st>>>(x, bstride, partial, C, P, nblk);
-    reduce_partials_kernel<<<grid1d(C), 256, 0, st>>>(partial, out, B * nblk, (size_t)C, accumulate);
+    reduce_partials_kernel<<<red_grid(C), 256, 0, st>>>(partial, out, B * nblk, (size_t)C, accumulate);
     return check_launch("chan_sum");
 }
 
@@ -390,7 +465,7 @@ int launch_ln_bwd(const float* x, const float* dy, const float* gamma, float* dx
     ProfScope prof(st, "ln_bwd(2 kernels)", 14.0 * B * C * P, 20.0 * B * C * P);
     ln_bwd_kernel<<<dim3((unsigned)cdiv(P, 256), (unsigned)B), 256, 0, st>>>(x, dy, gamma, dx, stats, C, P, eps, accumulate_dx);
     ln_wgrad_kernel<<<dim3((unsigned)nblk, (unsigned)C, (unsigned)B), 256, 0, st>>>(x, dy, stats, sums, C, P, nblk);
-    reduce_partials_kernel<<<grid1d(2 * C), 256, 0, st>>>(sums, dgb, B * nblk, (size_t)2 * C, accumulate_w);
+    reduce_partials_kernel<<<red_grid(2 * C), 256, 0, st>>>(sums, dgb, B * nblk, (size_t)2 * C, accumulate_w);
     return check_launch("ln_bwd");
 }
 size_t ln_bwd_partial_floats(int B, int C, int P) { return align_up((size_t)B * 2 * P, 64) + (size_t)B * ln_nblk(P) * 2 * C; }
@@ -402,8 +477,11 @@ size_t dw_wgrad_partial_floats(int B, int C, int P) { return (size_t)B * dw_wgra
 int launch_dw_wgrad(const float* x, const float* dy, float* dw, float* db, float* partial, int B, int C, int h, int w, int accumulate, hipStream_t st) {
     const int nblk = dw_wgrad_nblk(h * w);
     ProfScope prof(st, "dw_wgrad_kernel", 20.0 * B * C * h * w, 8.0 * B * C * h * w);
-    dw_wgrad_kernel<<<dim3((unsigned)nblk, (unsigned)C, (unsigned)B), 256, 0, st>>>(x, dy, partial, C, h, w, nblk);
-    reduce_dw_kernel<<<grid1d((size_t)C * 10), 256, 0, st>>>(partial, dw, db, B * nblk, C, accumulate);
+    if (w % 4 == 0 && aligned16(x) && aligned16(dy) && ((size_t)h * w) % 4 == 0)
+        dw_wgrad_kernel<4><<<dim3((unsigned)nblk, (unsigned)C, (unsigned)B), 256, 0, st>>>(x, dy, partial, C, h, w, nblk);
+    else
+        dw_wgrad_kernel<1><<<dim3((unsigned)nblk, (unsigned)C, (unsigned)B), 256, 0, st>>>(x, dy, partial, C, h, w, nblk);
+    reduce_dw_kernel<<<red_grid((size_t)C * 10), 256, 0, st>>>(partial, dw, db, B * nblk, C, accumulate);
     return check_launch("dw_wgrad");
 }
 
@@ -471,15 +549,27 @@ __global__ void __launch_bounds__(256) flca_se_bwd_kernel(const float* __restric
                                                           float* __restrict__ dmP, float* __restrict__ gw1, float* __restrict__ gb1, float* __restrict__ gw3, float* __restrict__ gb3,
                                                           int B, int C, int hid, int P) {
     __shared__ float mean[512], dch[512], ds3[512], hv[64], dh[64];
+    __shared__ float colsum[8][64];
     for (int b = 0; b < B; ++b) {
-        for (int c = threadIdx.x; c < C; c += 256) {
+        // column sums of the two partial tables: 64 channels x 4 row parts per pass, parts combined in a fixed order
+        // (one thread per channel walking up to 1024 rows made this kernel 240 us)
+        for (int c0 = 0; c0 < C; c0 += 64) {
+            const int c = c0 + (threadIdx.x & 63), part = threadIdx.x >> 6;
             float s = 0.f, d = 0.f;
-            for (int k = 0; k < pool_nblk; ++k) s += pool_partial[((size_t)b * pool_nblk + k) * C + c];
-            for (int k = 0; k < dch_nblk; ++k) d += dch_partial[((size_t)b * dch_nblk + k) * C + c];
-            mean[c] = s / (float)P;
-            dch[c] = d;
+            if (c < C) {
+                for (int k = part; k < pool_nblk; k += 4) s += pool_partial[((size_t)b * pool_nblk + k) * C + c];
+                for (int k = part; k < dch_nblk; k += 4) d += dch_partial[((size_t)b * dch_nblk + k) * C + c];
+            }
+            colsum[part][threadIdx.x & 63] = s;
+            colsum[4 + part][threadIdx.x & 63] = d;
+            __syncthreads();
+            if (part == 0 && c < C) {
+                const int l = threadIdx.x & 63;
+                mean[c] = (((colsum[0][l] + colsum[1][l]) + colsum[2][l]) + colsum[3][l]) / (float)P;
+                dch[c] = ((colsum[4][l] + colsum[5][l]) + colsum[6][l]) + colsum[7][l];
+            }
+            __syncthreads();
         }
-        __syncthreads();
         for (int m = threadIdx.x; m < hid; m += 256) {
             float s = b1[m];
             for (int c = 0; c < C; ++c) s = fmaf(w1[m * C + c], mean[c], s);
@@ -576,12 +666,21 @@ __global__ void __launch_bounds__(256) flca_spatial_bwd_kernel(FlcaBwdArgs a) {
         a.abg_partial[(b * a.nblk + blk) * 3 + threadIdx.x] = (red[threadIdx.x][0] + red[threadIdx.x][1]) + (red[threadIdx.x][2] + red[threadIdx.x][3]);
 }
 
-__global__ void flca_abg_kernel(const float* __restrict__ partial, int nrec, float* __restrict__ ga, float* __restrict__ gb, float* __restrict__ gg) {
+__global__ void __launch_bounds__(256) flca_abg_kernel(const float* __restrict__ partial, int nrec, float* __restrict__ ga, float* __restrict__ gb, float* __restrict__ gg) {
+    __shared__ float part[3][256];
+    float s[3] = {0.f, 0.f, 0.f};
+    for (int k = threadIdx.x; k < nrec; k += 256) {
+#pragma unroll
+        for (int t = 0; t < 3; ++t) s[t] += partial[(size_t)k * 3 + t];
+    }
+#pragma unroll
+    for (int t = 0; t < 3; ++t) part[t][threadIdx.x] = s[t];
+    __syncthreads();
     if (threadIdx.x < 3) {
-        float s = 0.f;
-        for (int k = 0; k < nrec; ++k) s += partial[(size_t)k * 3 + threadIdx.x];
+        float v = 0.f;
+        for (int q = 0; q < 256; ++q) v += part[threadIdx.x][q];      // fixed order
         float* o = threadIdx.x == 0 ? ga : threadIdx.x == 1 ? gb : gg;
-        *o += s;
+        *o += v;
     }
 }
 
@@ -611,7 +710,7 @@ int launch_flca_backward(const float* feat, const float* guide, const float* xs,
         flca_se_bwd_kernel<<<1, 256, 0, st>>>(pool_partial, pool_nblk, dch_part, dnblk, prm[6], prm[7], prm[8], prm[9], dmP, grd[6], grd[7], grd[8], grd[9], B, C, hid, P);
         FlcaBwdArgs a{feat, guide, dz, dz_bstride, ch, dmP, prm[3], prm[4], prm[5], prm[0], prm[1], prm[2], dfeat, ds, abg, B, C, h, w, nblk, accumulate};
         flca_spatial_bwd_kernel<<<dim3((unsigned)nblk, (unsigned)B), 256, 0, st>>>(a);
-        flca_abg_kernel<<<1, 64, 0, st>>>(abg, B * nblk, grd[0], grd[1], grd[2]);
+        flca_abg_kernel<<<1, 256, 0, st>>>(abg, B * nblk, grd[0], grd[1], grd[2]);
         if (int rc = check_launch("flca_backward")) return rc;
     }
     // tap sums = 3x3 weight gradients with the guidance planes as (1- or 2-channel) inputs
