@@ -57,42 +57,74 @@ __global__ void __launch_bounds__(256) gram2_kernel(Gram2Args g) {
 #pragma unroll
         for (int t = 0; t < TJ; ++t) acc[k][t] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-    // the 4 pixels of a lane sit in one row (w % 4 == 0); neighbours along x come from the aligned groups left and right
-    auto shifted = [&](const float* row, int y, int x, int sy, int sx, float (&v)[4]) {
-        const int yy = y + sy;
-        if (yy < 0 || yy >= h) { v[0] = v[1] = v[2] = v[3] = 0.f; return; }
-        const float* p = row + (size_t)yy * w + x;
-        const float4 c = ld4(p);
-        if (sx == 0) { v[0] = c.x; v[1] = c.y; v[2] = c.z; v[3] = c.w; }
-        else if (sx < 0) { const float l = x > 0 ? p[-1] : 0.f; v[0] = l; v[1] = c.x; v[2] = c.y; v[3] = c.z; }
-        else { const float rr = x + 4 < w ? p[4] : 0.f; v[0] = c.y; v[1] = c.z; v[2] = c.w; v[3] = rr; }
-    };
-    // the loop is wave-uniform: an MFMA takes its operands from ALL 64 lanes whatever EXEC says, so lanes past the end of the
-    // slab stay in the loop and feed zeros (clamped address, masked value)
-    for (int n0 = n_lo + wave * 16; n0 < n_hi; n0 += 64) {
+    // The 4 pixels of a lane sit in one row (w % 4 == 0).  A step's loads -- the A row, and per B tile three rows of (16 bytes +
+    // the two outer taps) for the 3x3 window, or one shifted row -- are all UNCONDITIONAL on clamped addresses (values masked
+    // afterwards) and issued one step ahead: loads behind `if (row inside the image)` branches had been followed by
+    // s_waitcnt vmcnt(0) each, 15 serialised round trips per step (gram2<9> ran at 16 % of the f32 matrix rate).
+    constexpr int NROW = NTAP == 9 ? 3 : 1;
+    struct Step { float4 a; float4 c[TJ][NROW]; float l[TJ][NROW], rg[TJ][NROW]; bool ok; bool rok[NROW]; bool lok, rgk; };
+    auto load_step = [&](Step& q, int n0) {
         const int nn = n0 + 4 * kq;
-        const bool ok = nn < n_hi;
-        const int n = ok ? nn : n_lo;
+        q.ok = nn < n_hi;
+        const int n = q.ok ? nn : n_lo;
         const int y = n / w, x = n - y * w;
-        const float4 av = ld4(arow + n);
-        const float aa[4] = {ok ? av.x : 0.f, ok ? av.y : 0.f, ok ? av.z : 0.f, ok ? av.w : 0.f};
+        q.a = ld4(arow + n);
+        q.lok = x > 0; q.rgk = x + 4 < w;
 #pragma unroll
-        for (int t = 0; t < TJ; ++t) {
-            if constexpr (NTAP == 1) {
-                float bv[4];
-                shifted(brow[t], y, x, g.sy, g.sx, bv);
+        for (int dy = 0; dy < NROW; ++dy) {
+            const int yy = y + (NTAP == 9 ? dy - 1 : g.sy);
+            q.rok[dy] = q.ok && yy >= 0 && yy < h;
+            const size_t off = (size_t)(q.rok[dy] ? yy : 0) * w + x;
 #pragma unroll
-                for (int m = 0; m < 4; ++m) acc[0][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(aa[m], bv[m], acc[0][t], 0, 0, 0);
-            } else {
-#pragma unroll
-                for (int k = 0; k < 9; ++k) {
-                    float bv[4];
-                    shifted(brow[t], y, x, k / 3 - 1, k % 3 - 1, bv);
-#pragma unroll
-                    for (int m = 0; m < 4; ++m) acc[k][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(aa[m], bv[m], acc[k][t], 0, 0, 0);
+            for (int t = 0; t < TJ; ++t) {
+                const float* p = brow[t] + off;
+                q.c[t][dy] = ld4(p);
+                if constexpr (NTAP == 9) {        // the single-tap form only shifts rows (launch_gram2 checks sx == 0)
+                    q.l[t][dy] = p[q.lok ? -1 : 0];
+                    q.rg[t][dy] = p[q.rgk ? 4 : 0];
+                } else {
+                    q.l[t][dy] = 0.f; q.rg[t][dy] = 0.f;
                 }
             }
         }
+    };
+    auto compute = [&](const Step& q) {
+        const float aa[4] = {q.ok ? q.a.x : 0.f, q.ok ? q.a.y : 0.f, q.ok ? q.a.z : 0.f, q.ok ? q.a.w : 0.f};
+#pragma unroll
+        for (int t = 0; t < TJ; ++t) {
+            float v[NROW][6];
+#pragma unroll
+            for (int dy = 0; dy < NROW; ++dy) {
+                const bool rk = q.rok[dy];
+                v[dy][0] = (rk && q.lok) ? q.l[t][dy] : 0.f;
+                v[dy][1] = rk ? q.c[t][dy].x : 0.f; v[dy][2] = rk ? q.c[t][dy].y : 0.f;
+                v[dy][3] = rk ? q.c[t][dy].z : 0.f; v[dy][4] = rk ? q.c[t][dy].w : 0.f;
+                v[dy][5] = (rk && q.rgk) ? q.rg[t][dy] : 0.f;
+            }
+            if constexpr (NTAP == 1) {
+#pragma unroll
+                for (int m = 0; m < 4; ++m) acc[0][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(aa[m], v[0][m + 1], acc[0][t], 0, 0, 0);
+            } else {
+#pragma unroll
+                for (int k = 0; k < 9; ++k)
+#pragma unroll
+                    for (int m = 0; m < 4; ++m)
+                        acc[k][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(aa[m], v[k / 3][m + k % 3], acc[k][t], 0, 0, 0);
+            }
+        }
+    };
+    // the loop is wave-uniform: an MFMA takes its operands from ALL 64 lanes whatever EXEC says, so lanes past the end of the
+    // slab stay in the loop and feed zeros (clamped address, masked value)
+    Step s0, s1;
+    int n0 = n_lo + wave * 16;
+    if (n0 < n_hi) load_step(s0, n0);
+    for (; n0 < n_hi; n0 += 128) {
+        const bool more1 = n0 + 64 < n_hi;
+        if (more1) load_step(s1, n0 + 64);
+        compute(s0);
+        if (!more1) break;
+        if (n0 + 128 < n_hi) load_step(s0, n0 + 128);
+        compute(s1);
     }
     __shared__ float red[4][16][17];
 #pragma unroll
@@ -426,6 +458,7 @@ int launch_gram2(const float* a, int64_t a_bstride, int Ca, const float* b, int6
     RF_CHECK_ARG(w % 4 == 0 && aligned16(a) && aligned16(b) && a_bstride % 4 == 0 && b_bstride % 4 == 0,
                  "gram2: width %d must be a multiple of 4 and the operands 16-byte aligned", w);
     RF_CHECK_ARG(ntap == 1 || ntap == 9, "gram2: ntap must be 1 or 9");
+    RF_CHECK_ARG(ntap == 9 || sx == 0, "gram2: the single-tap form shifts rows only (sx = %d)", sx);
     Gram2Args g{a, a_bstride, Ca, b, b_bstride, Cb, partial, B, h, w, sy, sx, 0, 0};
     gram2_slabs(B, h * w, cdiv(Ca, 16) * cdiv(Cb, ntap == 1 ? 64 : 16), &g.slab_px, &g.slabs_per_image);
     const int nslab = B * g.slabs_per_image;
