@@ -106,9 +106,9 @@ int run_transformer(const TbParams& p, const float* in, float* out, float* ws, c
     RF_TRY(launch_conv1x1(av, st));
 
     // x + ffn(LN2(x)) ----------------------------------------------------------------------
-    if (!no_fuse_ffn && fused_ffn_supported(C, hc, hh, ww)) {
+    if (!no_fuse_ffn && p.pw1_wp3 && fused_ffn_supported(C, hc, hh, ww)) {
         // LN2 -> 1x1 -> depthwise 3x3 -> GELU -> 1x1 + residual in one kernel: the hidden tensor stays on chip
-        RF_TRY(launch_ffn_fused(x1, out, p.ln2_w, p.ln2_b, p.pw1_wp, p.pw1_b, p.dw_w, p.dw_b, p.pw2_wp, p.pw2_b, B, C, hh, ww, st));
+        RF_TRY(launch_ffn_fused(x1, out, p.ln2_w, p.ln2_b, p.pw1_wp3, p.pw1_b, p.dw_w, p.dw_b, p.pw2_wp, p.pw2_b, B, C, hh, ww, st));
     } else {
         Conv1x1Args f1{};
         f1.x1 = x1; f1.C1 = C; f1.x1_bstride = (int64_t)C * Pn;

@@ -232,7 +232,7 @@ int launch_attn_fold(const float* partial, int nslab, const float* temperature, 
 
 // ---- fused transformer-block kernels for C = 32 / 64 (rf_fused.hip)
 bool fused_ffn_supported(int C, int hidden, int h, int w);
-int launch_ffn_fused(const float* x, float* out, const float* ln_w, const float* ln_b, const float* w1p, const float* b1,
+int launch_ffn_fused(const float* x, float* out, const float* ln_w, const float* ln_b, const void* w1p /* b3 */, const float* b1,
                      const float* wd, const float* bd, const float* w2p, const float* b2, int B, int C, int h, int w, hipStream_t st);
 bool fused_attn_supported(int C, int heads, int h, int w);
 int fused_attn_plan(int h, int w, int* nslab, size_t* partial_floats, int B, int C);

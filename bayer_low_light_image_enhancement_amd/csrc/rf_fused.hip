@@ -312,7 +312,7 @@ struct FfnArgs {
     const float* x;        // [B][C][h][w] block input (also the residual)
     float* out;            // [B][C][h][w]
     const float* ln_w; const float* ln_b;
-    const float* w1p;      // packed [C/4][2C/16][64]
+    const void* w1p;       // b3-packed pw1 weight [C/32][2C/16][3][64] 16-byte elements
     const float* b1;       // [2C]
     const float* wd;       // [2C][9]
     const float* bd;       // [2C]
@@ -331,7 +331,7 @@ __global__ void __launch_bounds__(256, 2) ffn_fused_kernel(FfnArgs a) {
     constexpr int PS = 448;              // LDS plane stride (multiple of 64: kq planes on disjoint slots)
     // all weights live in LDS for the lifetime of the (persistent) workgroup
     __shared__ __attribute__((aligned(16))) float mid[PART * PS + 8];
-    __shared__ __attribute__((aligned(16))) float w1_l[NS * NT1 * 64];
+    __shared__ __attribute__((aligned(16))) u32x4 w1_l[(C / 32) * NT1 * 192];      // b3 form (phase A runs on the bf16 instruction)
     __shared__ __attribute__((aligned(16))) float w2_l[(2 * C / 4) * NTO * 64];
     __shared__ float wd_l[2 * C * 9], bd_l[2 * C], b1_l[2 * C], b2_l[C], gam_l[C], bet_l[C];
 
@@ -342,7 +342,7 @@ __global__ void __launch_bounds__(256, 2) ffn_fused_kernel(FfnArgs a) {
     const float* xb = a.x + (size_t)b * C * P;
     float* ob = a.out + (size_t)b * C * P;
 
-    for (int i = tid; i < NS * NT1 * 16; i += 256) *reinterpret_cast<float4*>(w1_l + i * 4) = *reinterpret_cast<const float4*>(a.w1p + i * 4);
+    for (int i = tid; i < (C / 32) * NT1 * 192; i += 256) w1_l[i] = reinterpret_cast<const u32x4*>(a.w1p)[i];
     for (int i = tid; i < (2 * C / 4) * NTO * 16; i += 256) *reinterpret_cast<float4*>(w2_l + i * 4) = *reinterpret_cast<const float4*>(a.w2p + i * 4);
     for (int i = tid; i < 2 * C * 9; i += 256) wd_l[i] = a.wd[i];
     for (int i = tid; i < 2 * C; i += 256) { bd_l[i] = a.bd[i]; b1_l[i] = a.b1[i]; }
@@ -350,33 +350,33 @@ __global__ void __launch_bounds__(256, 2) ffn_fused_kernel(FfnArgs a) {
     __syncthreads();
     STAMP_DECL
 
-    float4 xh0[NS], xh1[NS];
-    GroupGeom g0, g1;
     // A workgroup's tiles are CONSECUTIVE and numbered down the columns of the tile grid (ty fastest): successive tiles share two
     // of their six halo'd rows, which are then still in L2 (strided tiles, numbered along x, re-fetched every halo row from HBM)
     const int tiles_y = a.ntiles / a.tiles_x;
     const int per = (a.ntiles + (int)gridDim.x - 1) / (int)gridDim.x;
     const int t_begin = blockIdx.x * per, t_end = (t_begin + per < a.ntiles) ? t_begin + per : a.ntiles;
-    if (t_begin < t_end) {
-        const int tx = t_begin / tiles_y, ty = t_begin % tiles_y;
-        g0 = group_geom(wave, 0, j, ty * TH, tx * TW, h, w);
-        g1 = group_geom(wave, 1, j, ty * TH, tx * TW, h, w);
-        load_step<C>(xb, P, kq, g0, xh0);
-        load_step<C>(xb, P, kq, g1, xh1);
-    }
     for (int tile = t_begin; tile < t_end; ++tile) {
         const int tx = tile / tiles_y, ty = tile % tiles_y;
         const int x0 = tx * TW, y0 = ty * TH;
         STAMP(0);
-        // input tile (fetched behind the previous tile's last phase B): LayerNorm in registers
-        ln_step<C>(kq, gam_l, bet_l, 1e-5f, xh0);
-        ln_step<C>(kq, gam_l, bet_l, 1e-5f, xh1);
+        // input tile, loaded here (see attn_front_kernel: the b3 pieces take the registers a tile in flight would need):
+        // LayerNorm in registers, then the three-piece split that both parts of phase A reuse
+        const GroupGeom gw0 = group_geom(wave, 0, j, y0, x0, h, w), gw1 = group_geom(wave, 1, j, y0, x0, h, w);
+        u32x4 bp0[C / 32][4][3], bp1[C / 32][4][3];
+        {
+            float4 xh0[NS], xh1[NS];
+            load_step_b3<C>(xb, P, kq, gw0, xh0);
+            load_step_b3<C>(xb, P, kq, gw1, xh1);
+            ln_step_b3<C>(kq, gam_l, bet_l, 1e-5f, xh0);
+            ln_step_b3<C>(kq, gam_l, bet_l, 1e-5f, xh1);
+            split_step<C>(xh0, bp0);
+            split_step<C>(xh1, bp1);
+        }
         STAMP(1);
 
         const int yo = y0 + wave, xo = x0 + 4 * j;          // this lane's 4 output pixels
         const bool live = yo < h && xo < w;
         const unsigned voff = (unsigned)(4 * kq) * (unsigned)P + (unsigned)(live ? yo * w + xo : 0);
-        const GroupGeom gw0 = g0, gw1 = g1;                  // this tile's LDS geometry (g0/g1 move on to the next tile)
         float4 resv[NTO * 4];
         f32x4 acc[NTO][4];
 #pragma unroll
@@ -389,19 +389,11 @@ __global__ void __launch_bounds__(256, 2) ffn_fused_kernel(FfnArgs a) {
             lds_barrier();                                 // previous phase B is done with mid
             STAMP(0);
             // ---- phase A: hidden[32 of part][halo tile] = W1 x^ + b1 -> LDS
-            phase_a_step<C, NT1>(xh0, w1_l + lane, 2 * part, 2 * part + 1, b1_l + part * PART, b1_l + part * PART + 16, mid, PS, kq, gw0);
-            phase_a_step<C, NT1>(xh1, w1_l + lane, 2 * part, 2 * part + 1, b1_l + part * PART, b1_l + part * PART + 16, mid, PS, kq, gw1);
+            phase_a_step_b3<C, NT1>(bp0, w1_l + lane, 2 * part, 2 * part + 1, b1_l + part * PART, b1_l + part * PART + 16, mid, PS, kq, gw0);
+            phase_a_step_b3<C, NT1>(bp1, w1_l + lane, 2 * part, 2 * part + 1, b1_l + part * PART, b1_l + part * PART + 16, mid, PS, kq, gw1);
             STAMP(2);
             if (part == NPART - 1) {
-                // the input registers are dead now: fetch the next tile, and this tile's residual rows,
-                // behind the last phase B (all loads are issued before this tile's stores)
-                const int tn = tile + 1;
-                if (tn < t_end) {
-                    g0 = group_geom(wave, 0, j, (tn % tiles_y) * TH, (tn / tiles_y) * TW, h, w);
-                    g1 = group_geom(wave, 1, j, (tn % tiles_y) * TH, (tn / tiles_y) * TW, h, w);
-                    load_step<C>(xb, P, kq, g0, xh0);
-                    load_step<C>(xb, P, kq, g1, xh1);
-                }
+                // this tile's residual rows, behind the last phase B (issued before this tile's stores)
 #pragma unroll
                 for (int t = 0; t < NTO; ++t)
 #pragma unroll
@@ -448,10 +440,10 @@ bool fused_ffn_supported(int C, int hidden, int h, int w) {
     return C == 32 && hidden == 2 * C && (w % 4 == 0) && ((double)C * h * w * 4.0 < 4.0e9);
 }
 
-int launch_ffn_fused(const float* x, float* out, const float* ln_w, const float* ln_b, const float* w1p, const float* b1,
+int launch_ffn_fused(const float* x, float* out, const float* ln_w, const float* ln_b, const void* w1p, const float* b1,
                      const float* wd, const float* bd, const float* w2p, const float* b2, int B, int C, int h, int w, hipStream_t st) {
     RF_CHECK_ARG(fused_ffn_supported(C, 2 * C, h, w) && B <= 65535, "ffn_fused: unsupported shape C=%d %dx%d", C, h, w);
-    RF_CHECK_ARG(aligned16(x) && aligned16(out), "ffn_fused: buffers must be 16-byte aligned");
+    RF_CHECK_ARG(aligned16(x) && aligned16(out) && aligned16(w1p), "ffn_fused: buffers must be 16-byte aligned");
     FfnArgs a{x, out, ln_w, ln_b, w1p, b1, wd, bd, w2p, b2, B, h, w, cdiv(w, fused::TW), 0};
     a.ntiles = a.tiles_x * cdiv(h, fused::TH);
     int wgs = cdiv(512, B);                       // persistent: two workgroups per CU over the whole batch
