@@ -326,7 +326,7 @@ __global__ void __launch_bounds__(64 * NWV, (NWV >= 8 || NCO >= 3) ? 1 : 2) conv
 }
 
 template <int NCO>
-static void launch_rw(const Conv3x3Args& a, int ngroups, int vec, hipStream_t st) {
+static void launch_rw(const Conv3x3Args& a, int ngroups, int vec, bool small, hipStream_t st) {
     // Wide images (w > 32): 8 waves share one 18-tap weight slice, one workgroup per CU; a wave owns one pixel
     // row of 64 (NCO >= 3) or two (NCO <= 2: 16x64 tile, 144 MFMAs per barrier).  Narrow images fall back to
     // 4-wave tiles of 32x8 or 16x16 pixels.  Workgroups are persistent over tiles of one (image, output group).
@@ -337,7 +337,11 @@ static void launch_rw(const Conv3x3Args& a, int ngroups, int vec, hipStream_t st
         const int wgs = cdiv(ntiles, (int)((total + 255) / 256));      // one resident workgroup per CU
         return dim3((unsigned)(ngroups * wgs), (unsigned)a.B);
     };
-    if (NCO == 1 && lrw == 0 && a.h >= 16) {
+    if (small && lrw == 0) {
+        // few pixels (one frame at levels 2-3): 4-wave workgroups on 4x64 tiles, more of them
+        const int txs = cdiv(a.w, 64), ntiles = txs * cdiv(a.h, 4);
+        conv3x3_kernel<NCO, 0, 1, 4><<<grid_for_tiles(ntiles), 256, 0, st>>>(a, ngroups, txs, ntiles, vec);
+    } else if (NCO == 1 && lrw == 0 && a.h >= 16) {
         // one output tile: 16 waves of one row each (103 registers, four waves per SIMD cover each other's LDS and
         // barrier waits) beat 8 waves of two rows by 7 %; with NCO = 2 the same shape spills at the 128-register cap
         const int txs = cdiv(a.w, 64), ntiles = txs * cdiv(a.h, 16);
@@ -366,6 +370,18 @@ int launch_conv3x3(const Conv3x3Args& a, hipStream_t st) {
     const int NT = cdiv(a.Cout, 16);
     int nco = 4;
     if (NT % 4 != 0) nco = (NT % 3 == 0) ? 3 : (NT % 2 == 0 ? 2 : (NT == 1 ? 1 : 4));
+    // A launch that would put fewer than 128 workgroups on the 256 CUs (one frame at the deep levels: 8 tiles x 4 output
+    // groups at level 3) trades per-workgroup efficiency for parallelism: 4x64 tiles on 4-wave workgroups and fewer output tiles
+    // per workgroup.  Batches of 8 never come here (the grid already fills the chip).
+    bool small = false;
+    if (a.w > 32 && a.h >= 8) {
+        const long big = (long)cdiv(a.w, 64) * cdiv(a.h, nco <= 2 ? 16 : 8) * cdiv(NT, nco) * a.B;
+        if (big < 128) {
+            small = true;
+            const long t4 = (long)cdiv(a.w, 64) * cdiv(a.h, 4) * a.B;
+            while (nco > 1 && t4 * cdiv(NT, nco) < 192) nco = (nco == 4 || nco == 2) ? nco / 2 : 1;
+        }
+    }
     const int ngroups = cdiv(NT, nco);
     const int vec = (a.w % 4 == 0) && aligned16(a.out) && (a.out_bstride % 4 == 0);
     char key[64];
@@ -374,14 +390,15 @@ int launch_conv3x3(const Conv3x3Args& a, hipStream_t st) {
         const int wide = lrw == 0 && a.h >= 8;
         snprintf(key, sizeof(key), "conv3x3_kernel<%d, %d, %d, %d>", nco, lrw, (wide && a.h >= 8 * rpwb) ? rpwb : 1, wide ? 8 : 4);
         if (nco == 1 && lrw == 0 && a.h >= 16) snprintf(key, sizeof(key), "conv3x3_kernel<1, 0, 1, 16>");
+        if (small) snprintf(key, sizeof(key), "conv3x3_kernel<%d, 0, 1, 4>", nco);
     }
     const double px = (double)a.B * a.h * a.w;
     ProfScope prof(st, key, 18.0 * a.Cin * a.Cout * px, 4.0 * px * (a.Cin + a.Cout));
     switch (nco) {
-        case 4: launch_rw<4>(a, ngroups, vec, st); break;
-        case 3: launch_rw<3>(a, ngroups, vec, st); break;
-        case 2: launch_rw<2>(a, ngroups, vec, st); break;
-        default: launch_rw<1>(a, ngroups, vec, st); break;
+        case 4: launch_rw<4>(a, ngroups, vec, small, st); break;
+        case 3: launch_rw<3>(a, ngroups, vec, small, st); break;
+        case 2: launch_rw<2>(a, ngroups, vec, small, st); break;
+        default: launch_rw<1>(a, ngroups, vec, small, st); break;
     }
     return check_launch("conv3x3");
 }
