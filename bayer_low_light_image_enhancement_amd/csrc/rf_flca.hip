@@ -177,11 +177,11 @@ __device__ __forceinline__ float fast_tanh(float x) { return 1.0f - 2.0f * __bui
 template <int PX>   // pixels of a row per lane: 4 (w % 4 == 0) or 2 (w % 4 == 2, e.g. level 3 of a 2848 x 4256 frame: w = 266)
 __global__ void __launch_bounds__(256) flca_spatial_vec_kernel(FlcaSpatialArgs a, const float* __restrict__ w_low,
                                                                const float* __restrict__ w_high, const float* __restrict__ w_chr,
-                                                               const float* __restrict__ feat, float* __restrict__ xs) {
+                                                               const float* __restrict__ feat, float* __restrict__ xs, int cg) {
     const int blk = blockIdx.x;
     const size_t b = blockIdx.z;
     const int h = a.h, w = a.w, P = h * w, C = a.C;
-    const int c_lo = blockIdx.y * kFlcaCG, c_hi = (c_lo + kFlcaCG < C) ? c_lo + kFlcaCG : C;   // this workgroup's channels
+    const int c_lo = blockIdx.y * cg, c_hi = (c_lo + cg < C) ? c_lo + cg : C;   // this workgroup's channels (cg <= kFlcaCG)
     const int p = (blk * 256 + threadIdx.x) * PX;
     const bool live = p < P;
     const int y = live ? p / w : 0, x = live ? p - (p / w) * w : 0;
@@ -320,10 +320,13 @@ int launch_flca_spatial(const FlcaSpatialArgs& a, hipStream_t st) {
     const bool vec = (a.w % 2 == 0) && aligned16(a.feat) && aligned16(a.xs) && aligned16(a.guide) && ((size_t)a.h * a.w) % 2 == 0;
     RF_CHECK_ARG(vec || a.w % 2 != 0, "flca: feature / guidance buffers must be 16-byte aligned");
     ProfScope prof(st, vec ? (a.w % 4 == 0 ? "flca_spatial_vec_kernel" : "flca_spatial_vec_kernel<2>") : "flca_spatial_kernel", 80.0 * el, 8.0 * el);
+    // channels per workgroup: 32, or 8 when that leaves most of the chip idle (one frame: a lane then walks 8 channels instead
+    // of 32 -- the per-channel load -> gate -> store chain is what a small launch waits on)
+    const int cg = ((long)a.nblk * cdiv(a.C, kFlcaCG) * a.B < 512) ? 8 : kFlcaCG;
     if (vec && a.w % 4 == 0)
-        flca_spatial_vec_kernel<4><<<dim3((unsigned)a.nblk, (unsigned)cdiv(a.C, kFlcaCG), (unsigned)a.B), 256, 0, st>>>(a, a.w_low, a.w_high, a.w_chr, a.feat, a.xs);
+        flca_spatial_vec_kernel<4><<<dim3((unsigned)a.nblk, (unsigned)cdiv(a.C, cg), (unsigned)a.B), 256, 0, st>>>(a, a.w_low, a.w_high, a.w_chr, a.feat, a.xs, cg);
     else if (vec)
-        flca_spatial_vec_kernel<2><<<dim3((unsigned)a.nblk, (unsigned)cdiv(a.C, kFlcaCG), (unsigned)a.B), 256, 0, st>>>(a, a.w_low, a.w_high, a.w_chr, a.feat, a.xs);
+        flca_spatial_vec_kernel<2><<<dim3((unsigned)a.nblk, (unsigned)cdiv(a.C, cg), (unsigned)a.B), 256, 0, st>>>(a, a.w_low, a.w_high, a.w_chr, a.feat, a.xs, cg);
     else
         flca_spatial_kernel<<<dim3((unsigned)a.nblk, (unsigned)a.B), 256, 0, st>>>(a);
     return check_launch("flca_spatial");
