@@ -896,13 +896,17 @@ int launch_conv1x1(const Conv1x1Args& a, hipStream_t st) {
         // bf16x3 streaming kernel (K > 32: below that the resident-input f32 kernels are HBM-bound anyway)
         // 6 tiles per workgroup where that divides the output evenly; never with the LayerNorm prologue (that instantiation
         // needs 2 registers more than the 256 a wave has at two waves per SIMD)
-        const int nco = (!a.ln_w && (NT % 6 == 0 || (NT % 4 != 0 && NT > 8))) ? 6 : 4;
+        int nco = (!a.ln_w && (NT % 6 == 0 || (NT % 4 != 0 && NT > 8))) ? 6 : 4;
+        // one frame at levels 2-3: fewer than 256 workgroups -- two output tiles per workgroup instead of four fills more CUs
+        if (!a.ln_w && nco == 4 && NT % 2 == 0 && (long)cdiv(a.P, 256) * cdiv(NT, 4) * a.B < 256) nco = 2;
         const int ngroups = cdiv(NT, nco);
         dim3 grid((unsigned)(cdiv(a.P, 256) * ngroups), (unsigned)a.B, 1);
         snprintf(key, sizeof(key), "conv1x1_b3_kernel<%d, %s>", nco, a.ln_w ? "true" : "false");
         ProfScope prof(st, key, work_flops, work_bytes);
         if (nco == 6) {
             conv1x1_b3_kernel<6, false><<<grid, 256, 0, st>>>(a, ngroups);
+        } else if (nco == 2) {
+            conv1x1_b3_kernel<2, false><<<grid, 256, 0, st>>>(a, ngroups);
         } else {
             if (a.ln_w) conv1x1_b3_kernel<4, true><<<grid, 256, 0, st>>>(a, ngroups);
             else conv1x1_b3_kernel<4, false><<<grid, 256, 0, st>>>(a, ngroups);
