@@ -653,6 +653,7 @@ struct AttnMidArgs {
     const float* bd;       // [3C]
     int B, h, w, tiles_x, ntiles, nslab;
     int ylo, yhi;          // as AttnFrontArgs
+    int rgroups;           // gridDim.z: the rounds (Gram tiles, then v parts) are split over this many workgroups per slab
 };
 
 template <int C>
@@ -731,10 +732,13 @@ __global__ void __launch_bounds__(256, 2) attn_mid_kernel(AttnMidArgs a) {
     if (slab >= a.ntiles) return;                          // (whole workgroup)
     const int ntw = (a.ntiles - slab + a.nslab - 1) / a.nslab;      // tiles of this workgroup: slab, slab + nslab, ...
     f32x4 gq = {0.f, 0.f, 0.f, 0.f}, gnq = gq, gnk = gq;
+    // rounds of this workgroup: every round is independent (its own Gram partial or its own v channels), so a launch with few
+    // slabs (one frame) spreads them over gridDim.z workgroups per slab -- same partials, same results
+    const int rd_lo = (int)blockIdx.z * NR / a.rgroups, rd_hi = ((int)blockIdx.z + 1) * NR / a.rgroups;
     plan_tile(slab);
-    load_round(0);
+    load_round(rd_lo);
     __syncthreads();                                      // wd_l / bd_l visible
-    for (int rd = 0; rd < NR; ++rd) {
+    for (int rd = rd_lo; rd < rd_hi; ++rd) {
         for (int ti = 0; ti < ntw; ++ti) {
             const int tile = slab + ti * a.nslab;
             const int x0 = (tile % a.tiles_x) * TW, y0 = (tile / a.tiles_x) * TH;
@@ -744,7 +748,7 @@ __global__ void __launch_bounds__(256, 2) attn_mid_kernel(AttnMidArgs a) {
             if (ti + 1 < ntw) {                           // next step: same round, next tile / next round, first tile
                 plan_tile(tile + a.nslab);
                 load_round(rd);
-            } else if (rd + 1 < NR) {
+            } else if (rd + 1 < rd_hi) {
                 plan_tile(slab);
                 load_round(rd + 1);
             }
@@ -825,11 +829,12 @@ int launch_attn_mid(const float* qkv, float* v, float* partial, int nslab, const
                     int B, int C, int h, int w, hipStream_t st, int ylo, int yhi) {
     RF_CHECK_ARG((C == 64 || C == 128) && w % 4 == 0 && B <= 65535, "attn_mid: unsupported shape C=%d %dx%d", C, h, w);
     RF_CHECK_ARG(aligned16(qkv) && aligned16(v), "attn_mid: buffers must be 16-byte aligned");
-    AttnMidArgs a{qkv, v, partial, wd, bd, B, h, w, cdiv(w, fused::TW), 0, nslab, ylo, (yhi > 0 && yhi < h) ? yhi : h};
+    AttnMidArgs a{qkv, v, partial, wd, bd, B, h, w, cdiv(w, fused::TW), 0, nslab, ylo, (yhi > 0 && yhi < h) ? yhi : h, 1};
     a.ntiles = a.tiles_x * cdiv(h, fused::TH);
+    if ((long)nslab * B < 256) a.rgroups = 3;               // C / 16 + C / 32 rounds: 6 (C = 64) or 12 (C = 128)
     const double px = (double)B * h * w;
     ProfScope prof(st, C == 64 ? "attn_mid_kernel<64>" : "attn_mid_kernel<128>", px * (54.0 * C + 4.0 * C * 16), px * 16.0 * C);
-    const dim3 grid((unsigned)nslab, (unsigned)B);
+    const dim3 grid((unsigned)nslab, (unsigned)B, (unsigned)a.rgroups);
     if (C == 64) attn_mid_kernel<64><<<grid, 256, 0, st>>>(a);
     else attn_mid_kernel<128><<<grid, 256, 0, st>>>(a);
     return check_launch("attn_mid");
