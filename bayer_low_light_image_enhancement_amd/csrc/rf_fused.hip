@@ -790,9 +790,11 @@ __global__ void __launch_bounds__(256, 2) attn_mid_kernel(AttnMidArgs a) {
             __syncthreads();
             float* red = mid;
             for (int i = tid; i < 64 * 48; i += 256) red[(i / 48) * ROWW + 16 + i % 48] = 0.f;      // zero key tiles: see attn_front_kernel
+            int kq_ = kq;                     // opaque here: the row addresses below were hoisted out of the round loop and SPILLED
+            asm volatile("" : "+v"(kq_));     // (scratch traffic next to the prefetched loads of the next round)
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
-                const int row = 4 * kq + q;
+                const int row = 4 * kq_ + q;
                 float* rr = red + (wave * 16 + row) * ROWW;
                 rr[j] = gq[q];
                 if (row == j) { rr[64] = gnq[q]; rr[65] = gnk[q]; }

@@ -917,6 +917,9 @@ int launch_conv1x1(const Conv1x1Args& a, hipStream_t st) {
         // are prefetched into registers
         int cap = (240 / ks) & ~1;
         if (a.res && cap > 4) cap = 4;
+        // the four-residual-tile instantiations with K <= 32 or a LayerNorm prologue spill (28-296 bytes of scratch) next to
+        // their prefetched loads: such shapes (no layer of RawFormer; reachable through rf_conv1x1) take two tiles per workgroup
+        if (a.res && (ks <= 8 || a.ln_w) && cap > 2) cap = 2;
         int ntw = NT < cap ? NT : cap;
         const int ngroups = cdiv(NT, ntw);
         const int tpad = cdiv(ntw, 2) * 2;
