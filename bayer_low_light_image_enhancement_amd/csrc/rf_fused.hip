@@ -705,8 +705,12 @@ __global__ void __launch_bounds__(256, 2) attn_mid_kernel(AttnMidArgs a) {
     auto load_round = [&](int rd) {
         const bool gram = rd < NQT;
         const size_t base = gram ? (size_t)16 * rd * P : (size_t)(2 * C + PART * (rd - NQT)) * P;
+        // num_records = the planes this round touches (q tile + k tile, C planes apart; or 32 v planes), never the rest of the
+        // tensor: it must stay below the OOB offset 2^31 for the zero fill to work on large frames (3C planes of a 1424x2128
+        // level are 2.3 GB)
+        const size_t span = (gram ? (size_t)(C + 16) : (size_t)PART) * P, rest = (size_t)3 * C * P - base;
         const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
-            const_cast<float*>(qb) + base, 0, (int)(((size_t)3 * C * P - base) * 4), 0x00020000);
+            const_cast<float*>(qb) + base, 0, (int)((span < rest ? span : rest) * 4), 0x00020000);
         const unsigned kjump = gram ? (unsigned)((C - 16) * P) * 4u : 0u;      // planes 16-31 of a Gram round are the k tile
 #pragma unroll
         for (int i = 0; i < FPT; ++i) {
@@ -824,7 +828,7 @@ int attn_mid_plan(int h, int w, int* nslab, size_t* partial_floats, int B, int C
 bool attn_mid_supported(int C, int heads, int h, int w) {
     const int c = heads > 0 ? C / heads : 0;
     return (C == 64 || C == 128) && heads > 0 && C % heads == 0 && c <= 16 && 16 % c == 0 && (w % 4 == 0) &&
-           ((double)3 * C * h * w * 4.0 < 2.0e9);
+           ((double)(C + 16) * h * w * 4.0 < 2.0e9);      // byte offsets inside one round's buffer window stay below 2^31
 }
 
 int launch_attn_mid(const float* qkv, float* v, float* partial, int nslab, const float* wd, const float* bd,
