@@ -118,7 +118,11 @@ def test_layernorm(ops, g, device):
 
 @pytest.mark.parametrize("c1,c2,cout,hw", [(32, 0, 96, (16, 16)), (64, 0, 32, (8, 24)), (16, 16, 16, (16, 8)),
                                            (48, 48, 48, (8, 8)), (256, 0, 768, (4, 4)), (24, 0, 80, (5, 7)),
-                                           (128, 128, 128, (16, 16)), (32, 0, 64, (64, 64))])
+                                           (128, 128, 128, (16, 16)), (32, 0, 64, (64, 64)),
+                                           # LayerNorm + 1x1 on conv1x1_b3_ln_kernel: K = 64 (a K block split over two waves), 128, 256;
+                                           # 2 / 3 / 4 output tiles per chunk; ragged last pixel tile; persistent workgroups (320 tiles)
+                                           (64, 0, 192, (24, 40)), (64, 0, 128, (9, 20)), (128, 0, 384, (160, 128)),
+                                           (128, 0, 256, (12, 20)), (256, 0, 512, (40, 48))])
 def test_conv1x1(ops, device, c1, c2, cout, hw):
     import torch.nn.functional as F
     x = rnd("c1.x", (2, c1) + hw)
