@@ -17,11 +17,17 @@ namespace rf {
 
 static constexpr int kUpNCOG = 2;    // output tiles (16 channels) per workgroup and sub-position
 
-size_t upcat_packed_floats(int C) {
+static bool upcat_b3(int C) { return (2 * C) % 32 == 0; }     // phase 1 on three-piece bf16 operands: whole K blocks of 32 channels
+static size_t upcat_f32_floats(int C) {
     const int ngrp = cdiv(cdiv(C, 16), kUpNCOG);
     const size_t wc = (size_t)(2 * C / 4) * ngrp * 4 * kUpNCOG * 64;
     const size_t wb = (size_t)(C / 4) * ngrp * kUpNCOG * 64;
     return wc + wb + (size_t)ngrp * kUpNCOG * 16;
+}
+// [Wc | Wb | b' | Wc in b3 form: [K block][T][piece][lane] 16-byte elements = 768 floats per (K block, tile)]
+size_t upcat_packed_floats(int C) {
+    const int ngrp = cdiv(cdiv(C, 16), kUpNCOG);
+    return upcat_f32_floats(C) + (upcat_b3(C) ? (size_t)(2 * C / 32) * ngrp * 4 * kUpNCOG * 768 : 0);
 }
 
 // packed Wc: [s = k/4][T = (grp*4 + ij)*NCOG + t][l],  l = i16 + 16 kk;  packed Wb: [s][grp*NCOG + t][l];  then b'
@@ -58,11 +64,24 @@ __global__ void __launch_bounds__(256) upcat_compose_kernel(const float* __restr
     }
 }
 
+// composed Wc (f32, MFMA operand order [s][T][l]) -> three bf16 pieces in the operand order of v_mfma_f32_16x16x32_bf16 (rf_common.h)
+__global__ void __launch_bounds__(256) upcat_b3_kernel(const float* __restrict__ wc, unsigned short* __restrict__ wc3, int C) {
+    const int ngrp = ((C + 15) / 16 + kUpNCOG - 1) / kUpNCOG;
+    const int NTc = ngrp * 4 * kUpNCOG, K = 2 * C;
+    const size_t total = (size_t)NTc * 16 * K;
+    for (size_t idx = blockIdx.x * 256ull + threadIdx.x; idx < total; idx += (size_t)gridDim.x * 256) {
+        const int k = (int)(idx % K), row = (int)(idx / K);          // row = 16 T + i
+        const float v = wc[((size_t)(k >> 2) * NTc + (row >> 4)) * 64 + (row & 15) + 16 * (k & 3)];
+        b3_store(wc3, NTc, row, k, v);
+    }
+}
+
 int pack_upcat(const float* up_w, const float* up_b, const float* cr_w, const float* cr_b, float* packed, int C, hipStream_t st) {
-    const size_t total = upcat_packed_floats(C);
+    const size_t total = upcat_f32_floats(C);
     int g = (int)((total + 255) / 256);
     if (g > 8192) g = 8192;
     upcat_compose_kernel<<<g, 256, 0, st>>>(up_w, up_b, cr_w, cr_b, packed, C);
+    if (upcat_b3(C)) upcat_b3_kernel<<<g, 256, 0, st>>>(packed, reinterpret_cast<unsigned short*>(packed + total), C);
     return check_launch("pack_upcat");
 }
 
@@ -73,16 +92,19 @@ struct UpcatArgs {
     const float* wc;     // packed composed convT weights
     const float* wb;     // packed skip weights
     const float* bias;   // b'
+    const void* wc3;     // Wc in b3 form (B3 kernels)
     int B, C, h, w, ngroups;
 };
 
-template <int NCOG>
+template <int NCOG, bool B3>
 __global__ void __launch_bounds__(256, 2) upcat_kernel(UpcatArgs a) {
     constexpr int KCX = 4, KCS = 2;                        // k-sets per chunk: 4 * 4 NCOG * 4 = 2 * 4 * NCOG * 4 = 128 MFMAs (NCOG = 2)
     constexpr int WX4 = KCX * 4 * NCOG * 16;               // float4 of weights per x chunk
     constexpr int WS4 = KCS * NCOG * 16;                   // ... per skip chunk
     constexpr int WPTX = (WX4 + 255) / 256;
-    __shared__ __attribute__((aligned(16))) float lds_w[2][WX4 * 4];
+    constexpr int W3 = 4 * NCOG * 192;                      // 16-byte elements of one K block's A pieces (b3 phase 1)
+    __shared__ __attribute__((aligned(16))) float lds_raw[B3 ? 2 * W3 * 4 : 2 * WX4 * 4];
+    float (*lds_w)[WX4 * 4] = reinterpret_cast<float (*)[WX4 * 4]>(lds_raw);      // f32 view (phase 2; phase 1 without b3)
     __shared__ float bias_l[NCOG * 16];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int j = lane & 15, kq = lane >> 4;
@@ -107,7 +129,67 @@ __global__ void __launch_bounds__(256, 2) upcat_kernel(UpcatArgs a) {
             for (int g = 0; g < 4; ++g) acc[ij][t][g] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
     // ---------------- phase 1: composed transposed convolution, K = 2C channels of x ----------------
-    {
+    if constexpr (B3) {
+        // K blocks of 32 channels on v_mfma_f32_16x16x32_bf16 with three-piece operands (rf_common.h): lane (j, kq) loads channels
+        // 32 c + 8 kq + i of its 4 pixels, splits them once per block (176 VALU) and feeds all 4 * NCOG accumulator tiles
+        // (192 MFMAs of 17 cycles per block instead of 256 of 33 for the f32 instruction)
+        typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+        u32x4* lw3 = reinterpret_cast<u32x4*>(lds_raw);
+        const u32x4* wg = reinterpret_cast<const u32x4*>(a.wc3);
+        const int nkb = 2 * C / 32;
+        constexpr int WPT3 = (W3 + 255) / 256;
+        const float* xb = a.x + b * 2 * C * (size_t)P + (size_t)(8 * kq) * P + pc;
+        float4 xr[8];
+        u32x4 wr[WPT3];
+        auto load_x = [&](int c) __attribute__((always_inline)) {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) xr[i] = *reinterpret_cast<const float4*>(xb + (size_t)(32 * c + i) * P);
+        };
+        auto load_w = [&](int c) __attribute__((always_inline)) {
+#pragma unroll
+            for (int i = 0; i < WPT3; ++i) {
+                const int idx = tid + 256 * i;                         // (T, piece, lane) of this group's slice: contiguous in wc3
+                wr[i] = wg[((size_t)c * NTc + grp * 4 * NCOG) * 192 + (idx < W3 ? idx : 0)];
+            }
+        };
+        auto store_w = [&](int buf) __attribute__((always_inline)) {
+#pragma unroll
+            for (int i = 0; i < WPT3; ++i)
+                if (tid + 256 * i < W3) lw3[buf * W3 + tid + 256 * i] = wr[i];
+        };
+        load_x(0);
+        load_w(0);
+        store_w(0);
+        __syncthreads();
+        for (int c = 0; c < nkb; ++c) {
+            u32x4 bp[4][3];
+#pragma unroll
+            for (int hp = 0; hp < 4; ++hp) {
+                const float xa[4] = {xr[2 * hp].x, xr[2 * hp].y, xr[2 * hp].z, xr[2 * hp].w};
+                const float xc[4] = {xr[2 * hp + 1].x, xr[2 * hp + 1].y, xr[2 * hp + 1].z, xr[2 * hp + 1].w};
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    unsigned a0, a1, a2, b0, b1, b2;
+                    b3_split(xa[g], a0, a1, a2);
+                    b3_split(xc[g], b0, b1, b2);
+                    bp[g][0][hp] = b3_pack(a0, b0);
+                    bp[g][1][hp] = b3_pack(a1, b1);
+                    bp[g][2][hp] = b3_pack(a2, b2);
+                }
+            }
+            const int cn = c + 1 < nkb ? c + 1 : c;                    // branch-free prefetch (the last one re-reads)
+            load_x(cn);
+            load_w(cn);
+            const u32x4* wl = lw3 + (c & 1) * W3 + lane;
+#pragma unroll
+            for (int T = 0; T < 4 * NCOG; ++T) {
+                const u32x4 ap[3] = {wl[(T * 3 + 0) * 64], wl[(T * 3 + 1) * 64], wl[(T * 3 + 2) * 64]};
+                b3_mfma4(ap, bp, acc[T / NCOG][T % NCOG]);
+            }
+            if (c + 1 < nkb) store_w((c + 1) & 1);
+            __syncthreads();
+        }
+    } else {
         const float* xb = a.x + b * 2 * C * (size_t)P + (size_t)kq * P + pc;
         float4 xa[KCX], xn[KCX], wr[WPTX];
         auto load_x = [&](int c, float4 (&dst)[KCX]) __attribute__((always_inline)) {
@@ -254,10 +336,12 @@ int launch_upcat(const float* x, const float* skip, float* out, const float* pac
     a.wc = packed;
     a.wb = packed + (size_t)(2 * C / 4) * ngrp * 4 * kUpNCOG * 64;
     a.bias = a.wb + (size_t)(C / 4) * ngrp * kUpNCOG * 64;
+    a.wc3 = packed + upcat_f32_floats(C);
     a.B = B; a.C = C; a.h = h; a.w = w; a.ngroups = ngrp;
     const double px = (double)B * h * w;
-    ProfScope prof(st, "upcat_kernel<2>", px * 24.0 * C * C, px * 4.0 * (2.0 * C + 8.0 * C));
-    upcat_kernel<kUpNCOG><<<dim3((unsigned)(cdiv(h * w, 256) * ngrp), (unsigned)B), 256, 0, st>>>(a);
+    ProfScope prof(st, upcat_b3(C) ? "upcat_kernel<2, true>" : "upcat_kernel<2, false>", px * 24.0 * C * C, px * 4.0 * (2.0 * C + 8.0 * C));
+    if (upcat_b3(C)) upcat_kernel<kUpNCOG, true><<<dim3((unsigned)(cdiv(h * w, 256) * ngrp), (unsigned)B), 256, 0, st>>>(a);
+    else upcat_kernel<kUpNCOG, false><<<dim3((unsigned)(cdiv(h * w, 256) * ngrp), (unsigned)B), 256, 0, st>>>(a);
     return check_launch("upcat");
 }
 
