@@ -530,9 +530,12 @@ __global__ void __launch_bounds__(256, 2) attn_front_kernel(AttnFrontArgs a) {
     for (int i = tid; i < 3 * C; i += 256) { bd_l[i] = a.bd[i]; bq_l[i] = a.bq[i]; }
     for (int i = tid; i < C; i += 256) { gam_l[i] = a.ln_w[i]; bet_l[i] = a.ln_b[i]; }
 
-    f32x4 gq[NQT], gnq[NQT], gnk[NQT];
+    // |q_j|^2 and |k_j|^2 are plain per-lane sums of squares (2 VALU per value): as the diagonals of q q^T and k k^T on the matrix
+    // pipe they cost eight 33-cycle MFMAs per step for 32 useful numbers -- and MFMA time and VALU time add up on this chip
+    f32x4 gq[NQT];
+    float nq[NQT], nk[NQT];
 #pragma unroll
-    for (int r = 0; r < NQT; ++r) { gq[r] = (f32x4){0.f, 0.f, 0.f, 0.f}; gnq[r] = gq[r]; gnk[r] = gq[r]; }
+    for (int r = 0; r < NQT; ++r) { gq[r] = (f32x4){0.f, 0.f, 0.f, 0.f}; nq[r] = 0.f; nk[r] = 0.f; }
     STAMP_DECL
 
     // consecutive tiles down the columns of the tile grid (see ffn_fused_kernel)
@@ -582,8 +585,8 @@ __global__ void __launch_bounds__(256, 2) attn_front_kernel(AttnFrontArgs a) {
                 for (int m = 0; m < 4; ++m) {
                     const float qv = ok ? qa[m] : 0.f, kv = ok ? kb[m] : 0.f;
                     gq[r] = __builtin_amdgcn_mfma_f32_16x16x4f32(qv, kv, gq[r], 0, 0, 0);
-                    gnq[r] = __builtin_amdgcn_mfma_f32_16x16x4f32(qv, qv, gnq[r], 0, 0, 0);
-                    gnk[r] = __builtin_amdgcn_mfma_f32_16x16x4f32(kv, kv, gnk[r], 0, 0, 0);
+                    nq[r] = fmaf(qv, qv, nq[r]);
+                    nk[r] = fmaf(kv, kv, nk[r]);
                 }
             }
             STAMP(3);
@@ -606,7 +609,8 @@ __global__ void __launch_bounds__(256, 2) attn_front_kernel(AttnFrontArgs a) {
                     const int hc = 4 * s + kq, cv = 2 * C + vp * PART + hc;
                     float v[4];
                     stencil4_dpp(mid + hc * PSV + wave * HC + 4 * j + 4, j, wd_l + cv * 9, bd_l[cv], v);
-                    *reinterpret_cast<float4*>(vb + (size_t)(vp * PART + hc) * P + (size_t)yo * w + xo) = make_float4(v[0], v[1], v[2], v[3]);
+                    // uniform base + 32-bit lane offset (C P < 2^30 elements, checked by fused_attn_supported): no 64-bit per-lane pointer to keep
+                    *reinterpret_cast<float4*>(vb + (unsigned)((vp * PART + hc) * P + yo * w + xo)) = make_float4(v[0], v[1], v[2], v[3]);
                 }
             }
             STAMP(4);
@@ -622,12 +626,16 @@ __global__ void __launch_bounds__(256, 2) attn_front_kernel(AttnFrontArgs a) {
 #pragma unroll
     for (int r = 0; r < NQT; ++r) {
         for (int i = tid; i < 64 * 48; i += 256) red[(i / 48) * ROWW + 16 + i % 48] = 0.f;
+        // channel j's sums of squares: the four kq lanes of a channel hold disjoint pixels
+        float nqt = nq[r], nkt = nk[r];
+        nqt += __shfl_xor(nqt, 16); nqt += __shfl_xor(nqt, 32);
+        nkt += __shfl_xor(nkt, 16); nkt += __shfl_xor(nkt, 32);
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             const int row = 4 * kq + q;
             float* rr = red + (wave * 16 + row) * ROWW;
             rr[j] = gq[r][q];
-            if (row == j) { rr[64] = gnq[r][q]; rr[65] = gnk[r][q]; }
+            if (row == j) { rr[64] = nqt; rr[65] = nkt; }
         }
         __syncthreads();
         float* dst = a.partial + (((size_t)b * a.nslab + slab) * NQT + r) * 16 * ROWW;
@@ -784,7 +792,8 @@ __global__ void __launch_bounds__(256, 2) attn_mid_kernel(AttnMidArgs a) {
         return;
     }
     const int ntw = (t_begin + per < a.ntiles) ? per : a.ntiles - t_begin;      // tiles of this workgroup: t_begin, t_begin + 1, ...
-    f32x4 gq = {0.f, 0.f, 0.f, 0.f}, gnq = gq, gnk = gq;
+    f32x4 gq = {0.f, 0.f, 0.f, 0.f};
+    float nq = 0.f, nk = 0.f;                              // sums of squares on the VALU (see attn_front_kernel)
     // rounds of this workgroup: every round is independent (its own Gram partial or its own v channels), so a launch with few
     // slabs (one frame) spreads them over gridDim.z workgroups per slab -- same partials, same results
     const int rd_lo = (int)blockIdx.z * NR / a.rgroups, rd_hi = ((int)blockIdx.z + 1) * NR / a.rgroups;
@@ -816,7 +825,7 @@ __global__ void __launch_bounds__(256, 2) attn_mid_kernel(AttnMidArgs a) {
             if (rd < NQT) {
                 // Gram: lane (i = j, kq) owns channel j of the q tile and of the k tile at pixels x0 + 16 st + 4 kq + m
                 const int cq = 16 * rd + j, ck = C + 16 * rd + j;
-#pragma unroll
+#pragma unroll 1
                 for (int st = 0; st < 4; ++st) {
                     const int xo = x0 + 16 * st + 4 * kq;
                     const bool ok = yo >= a.ylo && yo < a.yhi && xo < w;
@@ -827,8 +836,8 @@ __global__ void __launch_bounds__(256, 2) attn_mid_kernel(AttnMidArgs a) {
                     for (int m = 0; m < 4; ++m) {
                         const float qv = ok ? qa[m] : 0.f, kv = ok ? kb[m] : 0.f;
                         gq = __builtin_amdgcn_mfma_f32_16x16x4f32(qv, kv, gq, 0, 0, 0);
-                        gnq = __builtin_amdgcn_mfma_f32_16x16x4f32(qv, qv, gnq, 0, 0, 0);
-                        gnk = __builtin_amdgcn_mfma_f32_16x16x4f32(kv, kv, gnk, 0, 0, 0);
+                        nq = fmaf(qv, qv, nq);
+                        nk = fmaf(kv, kv, nk);
                     }
                 }
             } else {
@@ -852,18 +861,21 @@ __global__ void __launch_bounds__(256, 2) attn_mid_kernel(AttnMidArgs a) {
             for (int i = tid; i < 64 * 48; i += 256) red[(i / 48) * ROWW + 16 + i % 48] = 0.f;      // zero key tiles: see attn_front_kernel
             int kq_ = kq;                     // opaque here: the row addresses below were hoisted out of the round loop and SPILLED
             asm volatile("" : "+v"(kq_));     // (scratch traffic next to the prefetched loads of the next round)
+            float nqt = nq, nkt = nk;         // channel j's sums of squares over the four kq lanes
+            nqt += __shfl_xor(nqt, 16); nqt += __shfl_xor(nqt, 32);
+            nkt += __shfl_xor(nkt, 16); nkt += __shfl_xor(nkt, 32);
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
                 const int row = 4 * kq_ + q;
                 float* rr = red + (wave * 16 + row) * ROWW;
                 rr[j] = gq[q];
-                if (row == j) { rr[64] = gnq[q]; rr[65] = gnk[q]; }
+                if (row == j) { rr[64] = nqt; rr[65] = nkt; }
             }
             __syncthreads();
             float* dst = a.partial + (((size_t)b * a.nslab + slab) * NQT + rd) * 16 * ROWW;
             for (int i = tid; i < 16 * ROWW; i += 256)
                 dst[i] = ((red[i] + red[16 * ROWW + i]) + red[2 * 16 * ROWW + i]) + red[3 * 16 * ROWW + i];
-            gq = (f32x4){0.f, 0.f, 0.f, 0.f}; gnq = gq; gnk = gq;
+            gq = (f32x4){0.f, 0.f, 0.f, 0.f}; nq = 0.f; nk = 0.f;
         }
     }
 }
