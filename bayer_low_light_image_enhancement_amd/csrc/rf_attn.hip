@@ -74,7 +74,10 @@ __global__ void __launch_bounds__(256) gram_kernel(GramArgs a, int vec) {
     if (n_lo < a.p_lo) n_lo = a.p_lo;
     if (n_hi < n_lo) n_hi = n_lo;
 
-    f32x4 g[kMaxBand], nq = {0.f, 0.f, 0.f, 0.f}, nk = {0.f, 0.f, 0.f, 0.f};
+    // |q_i|^2, |k_i|^2: per-lane sums of squares on the VALU (as diagonals of two more MFMA products they cost 8 of the 12 MFMAs of a
+    // step at one band tile; MFMA and VALU time add up on gfx950)
+    f32x4 g[kMaxBand];
+    float nq = 0.f, nk = 0.f;
 #pragma unroll
     for (int t = 0; t < kMaxBand; ++t) g[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
@@ -100,7 +103,7 @@ __global__ void __launch_bounds__(256) gram_kernel(GramArgs a, int vec) {
     auto mfma_step = [&](const float4& qv, const float4 (&kv)[kMaxBand]) __attribute__((always_inline)) {
         const float qa[4] = {qv.x, qv.y, qv.z, qv.w};
 #pragma unroll
-        for (int m = 0; m < 4; ++m) nq = __builtin_amdgcn_mfma_f32_16x16x4f32(qa[m], qa[m], nq, 0, 0, 0);
+        for (int m = 0; m < 4; ++m) nq = fmaf(qa[m], qa[m], nq);
 #pragma unroll
         for (int t = 0; t < kMaxBand; ++t) {
             if (t < nb) {
@@ -109,7 +112,7 @@ __global__ void __launch_bounds__(256) gram_kernel(GramArgs a, int vec) {
                 for (int m = 0; m < 4; ++m) g[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(qa[m], kt[m], g[t], 0, 0, 0);
                 if (t == td) {
 #pragma unroll
-                    for (int m = 0; m < 4; ++m) nk = __builtin_amdgcn_mfma_f32_16x16x4f32(kt[m], kt[m], nk, 0, 0, 0);
+                    for (int m = 0; m < 4; ++m) nk = fmaf(kt[m], kt[m], nk);
                 }
             }
         }
@@ -150,14 +153,16 @@ __global__ void __launch_bounds__(256) gram_kernel(GramArgs a, int vec) {
 
     // cross-wave reduction in a fixed order, then one plain store per value
     __shared__ float red[4][16][kRowW];
+    nq += __shfl_xor(nq, 16); nq += __shfl_xor(nq, 32);       // channel i: the four kq lanes hold disjoint pixels
+    nk += __shfl_xor(nk, 16); nk += __shfl_xor(nk, 32);
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
         const int row = 4 * kq + r;
 #pragma unroll
         for (int t = 0; t < kMaxBand; ++t) red[wave][row][t * 16 + i] = g[t][r];
         if (row == i) {
-            red[wave][row][kMaxBand * 16] = nq[r];
-            red[wave][row][kMaxBand * 16 + 1] = nk[r];
+            red[wave][row][kMaxBand * 16] = nq;
+            red[wave][row][kMaxBand * 16 + 1] = nk;
         }
     }
     __syncthreads();
