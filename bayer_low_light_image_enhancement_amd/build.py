@@ -22,6 +22,9 @@ DIAG_LIB = os.path.join(CSRC, "librawformer_hip_diag.so")
 DIAG_SOURCES = ["rf_block.hip", "rf_model.hip", "rf_gemm1x1.hip"]
 SOURCES = ["rf_api.hip", "rf_model.hip", "rf_pack.hip", "rf_pointwise.hip", "rf_gemm1x1.hip",
            "rf_conv3x3.hip", "rf_attn.hip", "rf_flca.hip", "rf_fused.hip", "rf_block.hip", "rf_harness.hip", "rf_tokattn.hip", "rf_wfb.hip", "rf_upcat.hip", "rf_fft.hip", "rf_ffab.hip", "rf_truecolor.hip", "rf_train.hip", "rf_trainstep.hip"]
+# every header a source may include: ONE list for the product and the diagnostic objects (a stale *_diag.o linked with fresh
+# product objects would disagree on struct rf_handle)
+HEADERS = [os.path.join(CSRC, "rf_common.h"), os.path.join(CSRC, "rf_handle.h"), os.path.join(HERE, "..", "include", "rawformer_hip.h")]
 FLAGS = ["-O3", "-std=c++17", "-fPIC", "--offload-arch=gfx950", "-Wall", "-Wno-unused-function"]
 
 
@@ -41,7 +44,7 @@ def _stale(target: str, deps) -> bool:
 
 def build_library(force: bool = False, verbose: bool = False) -> str:
     hipcc = _hipcc()
-    headers = [os.path.join(CSRC, "rf_common.h"), os.path.join(CSRC, "rf_handle.h"), os.path.join(HERE, "..", "include", "rawformer_hip.h")]
+    headers = HEADERS
     objs, jobs = [], []
     for src in SOURCES:
         s = os.path.join(CSRC, src)
@@ -71,7 +74,7 @@ def build_diag_library(force: bool = False, verbose: bool = False) -> str:
     """``librawformer_hip_diag.so`` = the product objects with rf_block / rf_model rebuilt under -DRF_DIAG."""
     build_library(force=force, verbose=verbose)
     hipcc = _hipcc()
-    headers = [os.path.join(CSRC, "rf_common.h"), os.path.join(HERE, "..", "include", "rawformer_hip.h")]
+    headers = HEADERS
     objs, rebuilt = [], False
     for src in SOURCES:
         s = os.path.join(CSRC, src)

@@ -132,6 +132,16 @@ def profile_pass(fn, steps):
     return json.loads(buf.value.decode())
 
 
+def dry_profile_pass(fn, steps):
+    """``--dry-run`` stand-in of profile_pass: same control flow (the step is re-run ``steps`` times on the ranks that
+    profile), one synthetic record instead of HIP-event timings."""
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        fn()
+    ms = (time.perf_counter() - t0) * 1e3
+    return [{"kernel": "dry_run_step", "launches": steps, "ms": ms, "flops": 0.0, "bytes": 0.0}]
+
+
 def issued_over_algorithmic(kernel: str) -> float:
     """MFMA flops the kernel ISSUES per algorithmic flop.  The 3x3 convolutions use the Winograd F(4,3) form along x:
     6 products per 4 outputs x 3 taps instead of 12; the bf16x3 GEMM issues six bf16 products per
@@ -478,10 +488,20 @@ def main():
         line["config"]["optimizer"] = "AdamW lr 1e-4 weight_decay 1e-2; L1 loss"
         if trainer is not None:
             line["config"]["final_loss"] = round(float(out), 6)
-    if rank == 0 and not args.no_profile and not args.dry_run:
+    # The profiled pass re-runs ``step``.  When the step holds collectives (tile all-gather, the all-reduces inside
+    # forward_window, the gradient buckets) EVERY rank must run it or rank 0's collectives have no partner and the job
+    # hangs until the watchdog fires; only rank 0 keeps the records.  A collective-free step is profiled on rank 0 alone.
+    step_has_collectives = world > 1 and (tiled or exact or args.workload == "cfg5")
+    do_profile = not args.no_profile and (rank == 0 or step_has_collectives)
+    recs = None
+    if do_profile:
         prof_step = step if (tiled or exact or args.workload == "cfg5") else (lambda: forward(x))
         with torch.no_grad():
-            recs = profile_pass(prof_step, args.steps)
+            recs = (dry_profile_pass if args.dry_run else profile_pass)(prof_step, args.steps)
+        log(f"rank {rank}/{world}: profiled pass ran" + (" (step holds collectives: every rank takes part)" if step_has_collectives else ""))
+        if step_has_collectives:
+            fence()
+    if rank == 0 and recs:
         total = sum(r["ms"] for r in recs)
         recs.sort(key=lambda r: -r["ms"])
         top = recs[0]
@@ -501,7 +521,7 @@ def main():
                             "traffic": pmc_traffic(r["kernel"], args.workload)} for r in recs]
         line["profiled_ms_per_step"] = round(total / args.steps, 4)
         log("profiled pass done")
-        if args.workload == "cfg2":
+        if args.workload == "cfg2" and not args.dry_run:
             line["dwt_roofline"] = dwt_microbench(device)
             log("dwt microbench done")
     if rank == 0 and world == 1 and not args.no_cpu_baseline and not args.dry_run:

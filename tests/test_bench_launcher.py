@@ -23,6 +23,14 @@ def _json_line(stdout):
     return json.loads(lines[0])
 
 
+def _both_ranks_profiled(r, line):
+    """The profiled pass re-runs a step that holds collectives: both ranks must go through it (rank 0 alone would wait for
+    partners that never come) and rank 0 reports the records."""
+    for rk in (0, 1):
+        assert f"rank {rk}/2: profiled pass ran (step holds collectives" in r.stderr, r.stderr[-2000:]
+    assert "profiled_ms_per_step" in line and line["roofline"]["kernel"] == "dry_run_step"
+
+
 def test_gpus_2_launches_two_ranks_batch_sharded():
     r = _run("--gpus", "2", "--dry-run", "--steps", "2", "--warmup", "1")
     assert r.returncode == 0, r.stderr[-2000:]
@@ -32,6 +40,8 @@ def test_gpus_2_launches_two_ranks_batch_sharded():
     assert "rank 1/2" in r.stderr and "rank 0/2" in r.stderr        # both ranks really ran
     # whole-job value: both ranks' frames over the MAX time
     assert abs(line["value"] - 2 * 8 * 128 * 128 / 1e6 / (line["ms_per_step"] * 1e-3)) / line["value"] < 1e-3
+    # collective-free step: rank 0 profiles alone
+    assert "rank 0/2: profiled pass ran" in r.stderr and "rank 1/2: profiled pass ran" not in r.stderr
 
 
 def test_cfg4_two_ranks_tile_sharded_with_the_all_gather_in_the_step():
@@ -41,6 +51,7 @@ def test_cfg4_two_ranks_tile_sharded_with_the_all_gather_in_the_step():
     assert line["n_gpus"] == 2 and line["scaling"] == "strong"
     assert "tile-sharded x2" in line["config"]["parallelism"] and "all-gather" in line["config"]["parallelism"]
     assert ", 2 tiles" in r.stderr
+    _both_ranks_profiled(r, line)
 
 
 def test_cfg4x_two_ranks_exact_row_shards_with_their_collectives_in_the_step():
@@ -49,6 +60,7 @@ def test_cfg4x_two_ranks_exact_row_shards_with_their_collectives_in_the_step():
     line = _json_line(r.stdout)
     assert line["n_gpus"] == 2 and line["scaling"] == "strong"
     assert "exact row shards x2" in line["config"]["parallelism"] and "all-reduced" in line["config"]["parallelism"]
+    _both_ranks_profiled(r, line)
 
 
 def test_cfg5_two_ranks_rehearse_the_bucketed_gradient_all_reduce():
@@ -57,6 +69,7 @@ def test_cfg5_two_ranks_rehearse_the_bucketed_gradient_all_reduce():
     line = _json_line(r.stdout)
     assert line["n_gpus"] == 2 and line["scaling"] == "weak" and "training step" in line["metric"]
     assert "all-reduce" in line["config"]["parallelism"]
+    _both_ranks_profiled(r, line)
 
 
 def test_world_size_mismatch_is_refused():
