@@ -139,8 +139,10 @@ def forward_full_frame_sharded(forward: Callable[[torch.Tensor], torch.Tensor], 
 # ---- exact row sharding ---------------------------------------------------------------------------------------------
 # Receptive field of RawFormer along one axis, in packed (level-0) rows per side, when the global statistics are exact:
 # embedding 3x3 (1) + per stage {qkv depthwise 3x3, FFN depthwise 3x3, Conv_out 3x3} = 3 rows of its level + each
-# down-sampling 3x3 (1 row of its level): encoder 5 + 4*2 + 4*4 + 3*8, decoder 3*4 + 3*2 + 3, output 3x3 1 -> 75; FLCA's
-# guidance 3x3s sit in parallel with the TransformerBlock (1 row of their level).  80 = the next multiple of 8.
+# down-sampling 3x3 (1 row of its level): encoder 5 + 4*2 + 4*4 + 3*8, decoder 3*4 + 3*2 + 3, output 3x3 1 -> 75 rows for the
+# convolution chain.  FLCA's gates sit in parallel with the TransformerBlock (3x3 of their level on guidance planes that are
+# Haar bands of the luma, bilinearly resampled to the stage: up to 2 more level-0 rows at level 0); interval propagation
+# through the whole U-Net from 8-aligned cuts gives 77.  HALO_ROWS = 80 = the next multiple of 8: a margin of 3 rows.
 HALO_ROWS = 80
 
 

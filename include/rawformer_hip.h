@@ -86,7 +86,7 @@ int rf_forward(rf_handle* h, const float* in, float* out, void* workspace, size_
 
 /* Exact spatial sharding of ONE frame over several devices (the reference has no counterpart: it
  * runs whole frames on one device, test.py:116).  Each rank runs rf_forward on a WINDOW of the packed frame: its interior
- * rows [y_lo, y_hi) (local row indices, multiples of 8) plus enough halo rows for the U-Net's receptive field (76 packed rows)
+ * rows [y_lo, y_hi) (local row indices, multiples of 8) plus enough halo rows for the U-Net's receptive field (77 packed rows from 8-aligned cuts; tiling.HALO_ROWS = 80)
  * and the same window height on every rank.  What is global in RawFormer -- the channel attention's Gram / norm statistics
  * (FrequencyawareLumaChromaAttentionRAWFormer.py:205-221) and FLCA's squeeze-excite pooling (:150-154) -- is accumulated over the
  * interior rows only and reduced over the ranks through `allreduce(user, buf, n, op, stream)` (n floats, in place, ordered on

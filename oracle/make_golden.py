@@ -19,9 +19,11 @@ from __future__ import annotations
 
 import argparse
 import math
+import json
 import os
 import re
 import sys
+import time
 import types
 
 import numpy as np
@@ -559,6 +561,69 @@ def tiling_psnr(flca_mod):
     log(f"  wrote {os.path.relpath(path, REPO)}")
 
 
+def train_cfg5(flca_mod):
+    """BASELINE configs[4] (training step) pinned on the reference itself: the reference's own module
+    (FrequencyawareLumaChromaAttentionRAWFormer.RawFormer(dim=32), the model of train.py:105-106) under torch.autograd with the
+    reference's losses -- ``nn.L1Loss`` (RawFomer_WFB_FFAB/train.py:124) and ``CharbonnierLoss`` (train.py:16-25, its class
+    source executed from the file: the module itself imports the data loaders) -- and ``loss.backward()`` (train.py:143), at
+    config 5's own size (one 1024 x 1024 mosaic = packed 512 x 512) and on two 512 x 512 mosaics (several Gram slabs and
+    reduction blocks per image, two images).  Stored: loss, prediction samples, and per parameter tensor max|g|, ||g||_2, sum(g)
+    and 256 sampled entries; then one ``torch.optim.AdamW`` and one ``torch.optim.Adam`` step (train.py:113 uses Adam; the
+    BASELINE config names AdamW) on those gradients: 256 sampled updated weights per tensor."""
+    src = open(os.path.join(REF, "train.py")).read()
+    seg = src[src.index("class CharbonnierLoss"):src.index("if __name__ == '__main__':")]
+    ns = {"torch": torch, "nn": torch.nn}
+    exec(compile(seg, "train.py#CharbonnierLoss", "exec"), ns)
+    dim, pseed = 32, 132                                                    # the weights bench.py --workload cfg5 uses (100 + dim)
+    out = {}
+    for tag, b, hm, wm, seed, loss_name in (("1x1024", 1, 1024, 1024, 2, "l1"), ("2x1024", 2, 1024, 1024, 2, "l1"), ("2x512", 2, 512, 512, 40, "l1"), ("2x512c", 2, 512, 512, 40, "charbonnier")):
+        m = flca_mod.RawFormer(dim=dim)
+        synth.fill_state_dict(m.state_dict(), pseed)
+        m.train()
+        x = t(synth.bayer_mosaic(seed, b, hm, wm))
+        gt = t(synth.smooth_rgb(seed, b, hm, wm))
+        crit = torch.nn.L1Loss() if loss_name == "l1" else ns["CharbonnierLoss"]()
+        t0 = time.time()
+        pred = m(x)
+        loss = crit(pred, gt)
+        loss.backward()
+        log(f"f3  reference fwd+bwd {tag} ({loss_name}): loss {float(loss):.8f}  ({time.time() - t0:.1f} s)")
+        n = pred.numel()
+        idx = (synth.uniform01(7, "sample.idx", 4096).astype(np.float64) * n).astype(np.int64)
+        out[f"{tag}.loss"] = np.float64(float(loss))
+        out[f"{tag}.pred_idx"] = idx
+        out[f"{tag}.pred"] = pred.detach().reshape(-1)[idx].numpy()
+        out[f"{tag}.in_checksum"] = np.float64(checksum(x))
+        out[f"{tag}.gt_checksum"] = np.float64(checksum(gt))
+        names = [k for k, _ in m.named_parameters()]
+        gidx = {}
+        for k, p in m.named_parameters():
+            g = p.grad.detach().reshape(-1)
+            gi = (synth.uniform01(11, "grad.idx." + k, 256).astype(np.float64) * g.numel()).astype(np.int64)
+            gidx[k] = gi                                                      # regenerated by the test from (11, "grad.idx." + name)
+            out[f"{tag}.g.{k}.val"] = g[gi].numpy()
+            out[f"{tag}.g.{k}.stat"] = np.asarray([float(g.abs().max()), float(g.double().norm()), float(g.double().sum())])
+        if tag == "2x512":
+            # one optimiser step of each kind on exactly these gradients
+            before = {k: p.detach().clone() for k, p in m.named_parameters()}
+            grads = {k: p.grad.detach().clone() for k, p in m.named_parameters()}
+            for oname, mk in (("adamw", lambda ps: torch.optim.AdamW(ps, lr=1e-4, weight_decay=1e-2)), ("adam", lambda ps: torch.optim.Adam(ps, lr=1e-4))):
+                with torch.no_grad():
+                    for k, p in m.named_parameters():
+                        p.copy_(before[k]); p.grad = grads[k].clone()
+                opt = mk(list(m.parameters()))
+                opt.step()
+                for k, p in m.named_parameters():
+                    gi = gidx[k]
+                    out[f"{tag}.{oname}.{k}"] = (p.detach().reshape(-1)[gi] - before[k].reshape(-1)[gi]).numpy()     # the update itself
+        del m, pred, loss
+    out["param_seed"] = np.int64(pseed)
+    out["dim"] = np.int64(dim)
+    save("train_cfg5", **out)
+    with open(os.path.join(GOLD, "train_cfg5_params.json"), "w") as f:
+        json.dump(names, f)
+
+
 def state_dict_keys(flca_mod):
     """Key names and shapes of the reference's state_dict (what test.py:88-91 loads strictly)."""
     import json
@@ -581,6 +646,7 @@ def main():
     ap.add_argument("--only-cfg4", action="store_true", help="only BASELINE config 4 (RawFormer-L, one 2848x4256 mosaic)")
     ap.add_argument("--only-tiling", action="store_true", help="only tests/golden/tiling_psnr.json (config 4, tiled vs untiled reference; minutes of CPU)")
     ap.add_argument("--only-truecolor", action="store_true", help="only the TrueColorRawFormer fixtures (f4)")
+    ap.add_argument("--only-train", action="store_true", help="only tests/golden/train_cfg5.npz (reference autograd at config 5's size; ~20 GB, minutes)")
     ap.add_argument("--only-ffab", action="store_true", help="only the FEB / FFAB / rfft2 / WMB-wavelet-branch fixtures (f2)")
     args = ap.parse_args()
     if args.only_keys:
@@ -622,6 +688,12 @@ def main():
     if args.only_cfg4:
         torch.set_num_threads(8)
         config4(import_reference()[0])
+        return
+    if args.only_train:
+        torch.set_num_threads(8)
+        train_cfg5(import_reference()[0])
+        with open(os.path.join(GOLD, "PINNING.txt"), "a") as f:
+            f.write("\n".join(LOG) + "\n")
         return
     os.makedirs(GOLD, exist_ok=True)
     torch.manual_seed(0)
