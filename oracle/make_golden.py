@@ -587,10 +587,10 @@ def train_cfg5(flca_mod):
         pred = m(x)
         loss = crit(pred, gt)
         loss.backward()
-        log(f"f3  reference fwd+bwd {tag} ({loss_name}): loss {float(loss):.8f}  ({time.time() - t0:.1f} s)")
+        log(f"f3  reference fwd+bwd {tag} ({loss_name}): loss {float(loss.detach()):.8f}  ({time.time() - t0:.1f} s)")
         n = pred.numel()
         idx = (synth.uniform01(7, "sample.idx", 4096).astype(np.float64) * n).astype(np.int64)
-        out[f"{tag}.loss"] = np.float64(float(loss))
+        out[f"{tag}.loss"] = np.float64(float(loss.detach()))
         out[f"{tag}.pred_idx"] = idx
         out[f"{tag}.pred"] = pred.detach().reshape(-1)[idx].numpy()
         out[f"{tag}.in_checksum"] = np.float64(checksum(x))
@@ -603,6 +603,25 @@ def train_cfg5(flca_mod):
             gidx[k] = gi                                                      # regenerated by the test from (11, "grad.idx." + name)
             out[f"{tag}.g.{k}.val"] = g[gi].numpy()
             out[f"{tag}.g.{k}.stat"] = np.asarray([float(g.abs().max()), float(g.double().norm()), float(g.double().sum())])
+        if hm >= 1024:
+            # the reference again in float64: at this size its own float32 gradients carry summation noise of up to 4e-4 max|g|
+            # (262 144-pixel sums per bias gradient), so the samples the test trusts are these, and the float32 run tells how
+            # close a float32 implementation can be expected to come
+            m64 = flca_mod.RawFormer(dim=dim)
+            synth.fill_state_dict(m64.state_dict(), pseed)
+            m64.train().double()
+            t0 = time.time()
+            l64 = crit(m64(x.double()), gt.double())
+            l64.backward()
+            log(f"f3  reference fwd+bwd {tag} in float64: loss {float(l64.detach()):.10f}  ({time.time() - t0:.1f} s)")
+            out[f"{tag}.loss64"] = np.float64(float(l64.detach()))
+            worst = 0.0
+            for k, p in m64.named_parameters():
+                v64 = p.grad.detach().reshape(-1)[gidx[k]].numpy()
+                out[f"{tag}.g64.{k}.val"] = v64
+                worst = max(worst, float(np.abs(v64 - out[f"{tag}.g.{k}.val"]).max() / (out[f"{tag}.g.{k}.stat"][0] + 1e-30)))
+            log(f"f3  reference float32 vs float64 gradients {tag}: worst sampled |g32 - g64| / max|g| over the tensors = {worst:.2e}")
+            del m64, l64
         if tag == "2x512":
             # one optimiser step of each kind on exactly these gradients
             before = {k: p.detach().clone() for k, p in m.named_parameters()}
