@@ -156,29 +156,32 @@ def pipe_peak(kernel: str) -> float:
 
 
 def roofline_of(rec):
-    """``achieved`` = algorithmic work / measured time.  ``peak`` is the roof for THAT work:
-    8 TB/s for HBM-bound kernels; for MFMA-bound ones the f32 matrix peak divided by the issued/algorithmic ratio of
-    the kernel's algorithm, so ``frac`` = matrix-pipe utilisation and can never exceed 1."""
+    """Both floors of a kernel class and the one that binds.  ``frac_hbm`` = algorithmic bytes / time / 8 TB/s; ``frac_mfma`` =
+    the MFMA flops the kernel's algorithm ISSUES / time / the peak of the pipe it issues them on (f32: 157.3 TFLOP/s; the bf16x3
+    GEMMs: 2500 TFLOP/s with six products per f32 product; Winograd F(4,3): half the algorithmic flops).  ``bound`` is the
+    larger floor -- i.e. the ridge of the pipe actually used decides (52 flop/B for bf16x3, 19.7 for f32) -- ``frac`` its
+    fraction, never above 1; ``achieved`` / ``peak`` are in that bound's unit and price ALGORITHMIC work."""
     ms = rec["ms"] / rec["launches"]
     flops, byts = rec["flops"] / rec["launches"], rec["bytes"] / rec["launches"]
-    intensity = flops / max(byts, 1.0)
-    if intensity >= PEAK_F32_MFMA_TFLOPS * 1e12 / (PEAK_HBM_GBS * 1e9):
-        ratio = issued_over_algorithmic(rec["kernel"])
-        ach = flops / (ms * 1e-3) / 1e12
-        peak = pipe_peak(rec["kernel"]) / ratio
-        return {"kernel": rec["kernel"], "bound": "mfma", "achieved": round(ach, 3), "peak": round(peak, 1),
-                "unit": "TFLOP/s", "frac": round(ach / peak, 4), "traffic": None,
-                "avg_launch_us": round(ms * 1e3, 2), "launches_per_step": None,
-                "mfma_pipe_peak": pipe_peak(rec["kernel"]), "mfma_flops_issued_over_algorithmic": ratio,
-                "issued_tflops": round(ach * ratio, 3)}
-    ach = byts / (ms * 1e-3) / 1e9
-    return {"kernel": rec["kernel"], "bound": "hbm", "achieved": round(ach, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s",
-            "frac": round(ach / PEAK_HBM_GBS, 4), "traffic": None, "avg_launch_us": round(ms * 1e3, 2),
-            "launches_per_step": None}
+    ratio, pipe = issued_over_algorithmic(rec["kernel"]), pipe_peak(rec["kernel"])
+    t = ms * 1e-3
+    frac_hbm = byts / t / (PEAK_HBM_GBS * 1e9)
+    frac_mfma = flops * ratio / t / (pipe * 1e12)
+    common = {"kernel": rec["kernel"], "frac_hbm": round(frac_hbm, 4), "frac_mfma": round(frac_mfma, 4), "traffic": None,
+              "avg_launch_us": round(ms * 1e3, 2), "launches_per_step": None,
+              "floor_us": round(max(byts / (PEAK_HBM_GBS * 1e9), flops * ratio / (pipe * 1e12)) * 1e6, 2)}
+    if frac_mfma >= frac_hbm:
+        ach = flops / t / 1e12
+        return dict(common, bound="mfma", achieved=round(ach, 3), peak=round(pipe / ratio, 1), unit="TFLOP/s", frac=round(frac_mfma, 4),
+                    mfma_pipe_peak=pipe, mfma_flops_issued_over_algorithmic=ratio, issued_tflops=round(ach * ratio, 3))
+    return dict(common, bound="hbm", achieved=round(byts / t / 1e9, 1), peak=PEAK_HBM_GBS, unit="GB/s", frac=round(frac_hbm, 4))
 
 
-def _latest_profile(suffix: str):
-    files = sorted(glob.glob(os.path.join(REPO, "profiles", f"*_{suffix}.json")))
+def _latest_profile(suffix: str, workload: str):
+    """Newest committed ``profiles/*_<suffix>_<workload>.json`` (cfg2 also answers to the un-suffixed name of rounds 1-2)."""
+    files = sorted(glob.glob(os.path.join(REPO, "profiles", f"*_{suffix}_{workload}.json")))
+    if not files and workload == "cfg2":
+        files = sorted(glob.glob(os.path.join(REPO, "profiles", f"*_{suffix}.json")))
     if not files:
         return None
     try:
@@ -188,23 +191,19 @@ def _latest_profile(suffix: str):
 
 
 def pmc_traffic(kernel, workload):
-    """HBM bytes per launch of ``kernel`` from the committed rocprofv3 PMC passes of this same command
-    (profiles/*_traffic.json, made by tools/traffic.py: FETCH_SIZE and WRITE_SIZE in separate passes, gfx950
-    corrections applied).  PMC counters cannot be read from inside the process; None when the workload is not
-    the profiled one or the kernel is not in the file."""
-    if workload != "cfg2":
-        return None
-    d = _latest_profile("traffic")
+    """HBM bytes per launch of ``kernel`` from the committed rocprofv3 PMC passes of this same command and workload
+    (profiles/*_traffic_<workload>.json, made by tools/traffic.py: FETCH_SIZE and WRITE_SIZE in separate passes, gfx950
+    corrections applied).  PMC counters cannot be read from inside the process; None when no file covers the workload or the
+    kernel is not in it."""
+    d = _latest_profile("traffic", workload)
     rec = (d or {}).get("kernels", {}).get(kernel)
     return rec["hbm_bytes_per_launch"] if rec else None
 
 
 def pmc_mfma_util(kernel, workload):
-    """Matrix-pipe busy fraction of ``kernel`` from the committed SQ-counter pass (profiles/*_mfma_util.json,
-    made by tools/mfma_util.py from ``rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES ...``)."""
-    if workload != "cfg2":
-        return None
-    d = _latest_profile("mfma_util")
+    """Matrix-pipe busy fraction of ``kernel`` from the committed SQ-counter pass (profiles/*_mfma_util_<workload>.json,
+    made by tools/mfma_util.py from ``rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES ... GRBM_GUI_ACTIVE``)."""
+    d = _latest_profile("mfma_util", workload)
     rec = (d or {}).get("kernels", {}).get(kernel)
     return rec.get("mfma_busy_frac") if rec else None
 
@@ -512,14 +511,36 @@ def main():
         rl["algorithmic_bytes_per_launch"] = round(top["bytes"] / top["launches"])
         rl["share_of_forward"] = round(top["ms"] / total, 4)
         line["roofline"] = rl
-        line["kernels"] = [{"kernel": r["kernel"], "launches_per_step": r["launches"] // args.steps,
-                            "ms_per_step": round(r["ms"] / args.steps, 4), "share": round(r["ms"] / total, 4),
-                            "tflops": round(r["flops"] / max(r["ms"], 1e-9) / 1e9, 2),
-                            "gbs": round(r["bytes"] / max(r["ms"], 1e-9) / 1e6, 1),
-                            "frac": roofline_of(r)["frac"] if (r["flops"] or r["bytes"]) else None,
-                            "bound": roofline_of(r)["bound"] if (r["flops"] or r["bytes"]) else None,
-                            "traffic": pmc_traffic(r["kernel"], args.workload)} for r in recs]
+        rows, floor_ms, alg_bytes, pmc_bytes, pmc_cover_ms = [], 0.0, 0.0, 0.0, 0.0
+        for r in recs:
+            priced = bool(r["flops"] or r["bytes"])
+            rf = roofline_of(r) if priced else None
+            per_step = r["launches"] / args.steps
+            traffic = pmc_traffic(r["kernel"], args.workload)
+            rows.append({"kernel": r["kernel"], "launches_per_step": r["launches"] // args.steps,
+                         "ms_per_step": round(r["ms"] / args.steps, 4), "share": round(r["ms"] / total, 4),
+                         "tflops": round(r["flops"] / max(r["ms"], 1e-9) / 1e9, 2), "gbs": round(r["bytes"] / max(r["ms"], 1e-9) / 1e6, 1),
+                         "bound": rf["bound"] if rf else None, "frac": rf["frac"] if rf else None,
+                         "frac_hbm": rf["frac_hbm"] if rf else None, "frac_mfma": rf["frac_mfma"] if rf else None,
+                         "traffic": traffic, "mfma_util": pmc_mfma_util(r["kernel"], args.workload)})
+            if rf:
+                floor_ms += rf["floor_us"] * 1e-3 * per_step
+                alg_bytes += r["bytes"] / args.steps
+            if traffic is not None:
+                pmc_bytes += traffic * per_step
+                pmc_cover_ms += r["ms"] / args.steps
+        line["kernels"] = rows
         line["profiled_ms_per_step"] = round(total / args.steps, 4)
+        # the step as a whole: every kernel at its own binding roof (sum of floors) against what was measured, and the HBM bytes
+        # actually moved (PMC files of this workload, when committed) against the algorithmic bytes
+        line["forward_roofline"] = {
+            "sum_of_kernel_floors_ms": round(floor_ms, 4), "measured_ms_per_step": line["ms_per_step"],
+            "frac_of_floors": round(floor_ms / line["ms_per_step"], 4),
+            "algorithmic_gb_per_step": round(alg_bytes / 1e9, 3),
+            "pmc_hbm_gb_per_step": round(pmc_bytes / 1e9, 3) if pmc_bytes else None,
+            "pmc_covers_share_of_step": round(pmc_cover_ms / (total / args.steps), 4) if pmc_bytes else None,
+            "hbm_time_of_pmc_bytes_ms": round(pmc_bytes / (PEAK_HBM_GBS * 1e9) * 1e3, 4) if pmc_bytes else None,
+            "frac_hbm_whole_step": round(pmc_bytes / (PEAK_HBM_GBS * 1e9) * 1e3 / line["ms_per_step"], 4) if pmc_bytes else None}
         log("profiled pass done")
         if args.workload == "cfg2" and not args.dry_run:
             line["dwt_roofline"] = dwt_microbench(device)

@@ -8,7 +8,7 @@ mfma_busy_frac = SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE / 8 XCDs * 1024 SIM
 which the matrix pipe was executing (SQ_VALU_MFMA_BUSY_CYCLES counts cycles summed over SIMDs; GRBM_GUI_ACTIVE is summed over
 the 8 XCDs -- MI355X_MICROARCH.md).  MOPS counters are in units of 512 flops.
 
-usage: mfma_util.py <dir-or-counter_collection.csv> <out.json>
+usage: mfma_util.py <dir-or-counter_collection.csv> <out.json> [workload]
 """
 import collections
 import csv
@@ -53,7 +53,8 @@ def main():
                 if n in c:
                     rec[key] = round(c[n] / c["SQ_WAVE_CYCLES"], 4)
         out[k] = rec
-    json.dump({"source": "rocprofv3 --kernel-trace --pmc (SQ / GRBM counters, one pass) over bench.py cfg2",
+    wl = sys.argv[3] if len(sys.argv) > 3 else "cfg2"
+    json.dump({"source": f"rocprofv3 --kernel-trace --pmc (SQ / GRBM counters, one pass) over bench.py --workload {wl} --steps 2 --warmup 1", "workload": wl,
                "units": "per dispatch (mean over the dispatches of that kernel name)", "kernels": out}, open(out_path, "w"), indent=1)
     for k, v in out.items():
         if "mfma_busy_frac" in v:

@@ -8,7 +8,7 @@ convolution stages its input with dword gathers (halo rows, 264-byte runs): that
 the guide, so it is calibrated here on the level-0 launches, whose input bytes (+25 % halo at the 8x64 tile)
 are known: factor 1.3.
 
-usage: traffic.py <fetch counter_collection.csv> <write counter_collection.csv> <out.json>
+usage: traffic.py <fetch counter_collection.csv> <write counter_collection.csv> <out.json> [workload]
 """
 import collections
 import csv
@@ -41,7 +41,9 @@ def main():
         corr = 1.3 if k.startswith(DWORD_GATHER) else 2.0
         out[k] = {"launches_sampled": fetch[k][1], "fetch_size_kb_raw": round(f_kb, 1), "write_size_kb": round(w_kb, 1),
                   "fetch_correction": corr, "hbm_bytes_per_launch": round((f_kb * corr + w_kb) * 1024)}
-    json.dump({"source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) over bench.py cfg2, 2 steps",
+    wl = sys.argv[4] if len(sys.argv) > 4 else "cfg2"
+    json.dump({"source": f"rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) over bench.py --workload {wl} --steps 2 --warmup 1",
+               "workload": wl, "hbm_gb_per_step": round(sum(v["hbm_bytes_per_launch"] * v["launches_sampled"] for v in out.values()) / 3.0 / 1e9, 3),
                "units": "bytes per launch (mean over the launches of that kernel name in one forward)",
                "kernels": out}, open(sys.argv[3], "w"), indent=1)
     for k, v in out.items():
