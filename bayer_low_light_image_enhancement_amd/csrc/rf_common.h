@@ -292,10 +292,12 @@ int chan_sum_nblk(int P);
 int launch_chan_sum(const float* x, int64_t bstride, float* out, float* partial, int B, int C, int P, int accumulate, hipStream_t st);
 size_t ln_bwd_partial_floats(int B, int C, int P);
 int launch_ln_bwd(const float* x, const float* dy, const float* gamma, float* dx, float* dgb, float* partial,
-                  int B, int C, int P, float eps, int accumulate_dx, int accumulate_w, hipStream_t st);
+                  int B, int C, int P, float eps, int accumulate_dx, int accumulate_w, hipStream_t st,
+                  const float* res = nullptr, int64_t res_bstride = 0);
 size_t dw_wgrad_partial_floats(int B, int C, int P);
 int launch_dw_wgrad(const float* x, const float* dy, float* dw, float* db, float* partial, int B, int C, int h, int w, int accumulate, hipStream_t st);
 int launch_ewise(const float* a, const float* b, float* out, size_t n, int mode, float slope, hipStream_t st);
+int launch_split_halves(const float* src, float* a, float* b, int B, int C, int P, hipStream_t st);
 int launch_flip3x3(const float* w, float* out, int Cout, int Cin, int dense, hipStream_t st);
 int loss_nblk();
 int launch_loss(const float* pred, const float* gt, float* grad, float* loss_out, float* partial, size_t n, int mode, float eps, hipStream_t st);

@@ -34,26 +34,33 @@ struct Gram2Args {
     int B, h, w, sy, sx, slab_px, slabs_per_image;
 };
 
-template <int NTAP>
+// NA (single-tap form only): A tiles per workgroup.  With one A tile the B rows were re-read once per 16 output rows (Ca = 96:
+// 2.25 x the algorithmic bytes, 0.22 of HBM); NA = Ca / 16 (up to 6) reads both operands once.
+template <int NTAP, int NA>
 __global__ void __launch_bounds__(256) gram2_kernel(Gram2Args g) {
     constexpr int TJ = NTAP == 1 ? 4 : 1;
+    static_assert(NTAP == 1 || NA == 1, "several A tiles only in the single-tap form");
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int r = lane & 15, kq = lane >> 4;
     const int slab = blockIdx.x, ti = blockIdx.y, tjg = blockIdx.z;
     const int img = slab / g.slabs_per_image, sl = slab - img * g.slabs_per_image;
     const int h = g.h, w = g.w, P = h * w;
     const int n_lo = sl * g.slab_px, n_hi = (n_lo + g.slab_px < P) ? n_lo + g.slab_px : P;
-    const int ia = (16 * ti + r < g.Ca) ? 16 * ti + r : g.Ca - 1;
-    const float* arow = g.a + (size_t)img * g.a_bstride + (size_t)ia * P;
+    const float* arow[NA];
+#pragma unroll
+    for (int u = 0; u < NA; ++u) {
+        const int ia = 16 * (ti * NA + u) + r;
+        arow[u] = g.a + (size_t)img * g.a_bstride + (size_t)(ia < g.Ca ? ia : g.Ca - 1) * P;
+    }
     const float* brow[TJ];
 #pragma unroll
     for (int t = 0; t < TJ; ++t) {
         const int jb = 16 * (tjg * TJ + t) + r;
         brow[t] = g.b + (size_t)img * g.b_bstride + (size_t)(jb < g.Cb ? jb : g.Cb - 1) * P;
     }
-    f32x4 acc[NTAP][TJ];
+    f32x4 acc[NTAP * NA][TJ];       // [tap] (NA = 1) or [A tile] (NTAP = 1)
 #pragma unroll
-    for (int k = 0; k < NTAP; ++k)
+    for (int k = 0; k < NTAP * NA; ++k)
 #pragma unroll
         for (int t = 0; t < TJ; ++t) acc[k][t] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
@@ -62,13 +69,14 @@ __global__ void __launch_bounds__(256) gram2_kernel(Gram2Args g) {
     // afterwards) and issued one step ahead: loads behind `if (row inside the image)` branches had been followed by
     // s_waitcnt vmcnt(0) each, 15 serialised round trips per step (gram2<9> ran at 16 % of the f32 matrix rate).
     constexpr int NROW = NTAP == 9 ? 3 : 1;
-    struct Step { float4 a; float4 c[TJ][NROW]; float l[TJ][NROW], rg[TJ][NROW]; bool ok; bool rok[NROW]; bool lok, rgk; };
+    struct Step { float4 a[NA]; float4 c[TJ][NROW]; float l[TJ][NROW], rg[TJ][NROW]; bool ok; bool rok[NROW]; bool lok, rgk; };
     auto load_step = [&](Step& q, int n0) {
         const int nn = n0 + 4 * kq;
         q.ok = nn < n_hi;
         const int n = q.ok ? nn : n_lo;
         const int y = n / w, x = n - y * w;
-        q.a = ld4(arow + n);
+#pragma unroll
+        for (int u = 0; u < NA; ++u) q.a[u] = ld4(arow[u] + n);
         q.lok = x > 0; q.rgk = x + 4 < w;
 #pragma unroll
         for (int dy = 0; dy < NROW; ++dy) {
@@ -89,7 +97,9 @@ __global__ void __launch_bounds__(256) gram2_kernel(Gram2Args g) {
         }
     };
     auto compute = [&](const Step& q) {
-        const float aa[4] = {q.ok ? q.a.x : 0.f, q.ok ? q.a.y : 0.f, q.ok ? q.a.z : 0.f, q.ok ? q.a.w : 0.f};
+        float aa[NA][4];
+#pragma unroll
+        for (int u = 0; u < NA; ++u) { aa[u][0] = q.ok ? q.a[u].x : 0.f; aa[u][1] = q.ok ? q.a[u].y : 0.f; aa[u][2] = q.ok ? q.a[u].z : 0.f; aa[u][3] = q.ok ? q.a[u].w : 0.f; }
 #pragma unroll
         for (int t = 0; t < TJ; ++t) {
             float v[NROW][6];
@@ -103,13 +113,15 @@ __global__ void __launch_bounds__(256) gram2_kernel(Gram2Args g) {
             }
             if constexpr (NTAP == 1) {
 #pragma unroll
-                for (int m = 0; m < 4; ++m) acc[0][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(aa[m], v[0][m + 1], acc[0][t], 0, 0, 0);
+                for (int u = 0; u < NA; ++u)
+#pragma unroll
+                    for (int m = 0; m < 4; ++m) acc[u][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(aa[u][m], v[0][m + 1], acc[u][t], 0, 0, 0);
             } else {
 #pragma unroll
                 for (int k = 0; k < 9; ++k)
 #pragma unroll
                     for (int m = 0; m < 4; ++m)
-                        acc[k][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(aa[m], v[k / 3][m + k % 3], acc[k][t], 0, 0, 0);
+                        acc[k][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(aa[0][m], v[k / 3][m + k % 3], acc[k][t], 0, 0, 0);
             }
         }
     };
@@ -128,7 +140,7 @@ __global__ void __launch_bounds__(256) gram2_kernel(Gram2Args g) {
     }
     __shared__ float red[4][16][17];
 #pragma unroll
-    for (int k = 0; k < NTAP; ++k)
+    for (int k = 0; k < NTAP * NA; ++k)
 #pragma unroll
         for (int t = 0; t < TJ; ++t) {
             __syncthreads();
@@ -136,9 +148,10 @@ __global__ void __launch_bounds__(256) gram2_kernel(Gram2Args g) {
             for (int q = 0; q < 4; ++q) red[wave][4 * kq + q][r] = acc[k][t][q];
             __syncthreads();
             const int i = threadIdx.x >> 4, j = threadIdx.x & 15;       // 256 threads = the 16 x 16 tile
-            const int gi = 16 * ti + i, gj = 16 * (tjg * TJ + t) + j;
+            const int tap = NTAP == 1 ? 0 : k, u = NTAP == 1 ? k : 0;
+            const int gi = 16 * (ti * NA + u) + i, gj = 16 * (tjg * TJ + t) + j;
             if (gi < g.Ca && gj < g.Cb)
-                g.partial[(((size_t)slab * NTAP + k) * g.Ca + gi) * g.Cb + gj] = ((red[0][i][j] + red[1][i][j]) + red[2][i][j]) + red[3][i][j];
+                g.partial[(((size_t)slab * NTAP + tap) * g.Ca + gi) * g.Cb + gj] = ((red[0][i][j] + red[1][i][j]) + red[2][i][j]) + red[3][i][j];
         }
 }
 
@@ -210,10 +223,21 @@ __global__ void __launch_bounds__(256) reduce_dw_kernel(const float* __restrict_
 __global__ void __launch_bounds__(256) chan_sum_kernel(const float* __restrict__ x, int64_t bstride, float* __restrict__ partial, int C, int P, int nblk) {
     const int blk = blockIdx.x, c = blockIdx.y, img = blockIdx.z;
     const float* row = x + (size_t)img * bstride + (size_t)c * P;
-    const int per = (P + nblk - 1) / nblk;
+    const int per = ((P + nblk - 1) / nblk + 3) & ~3;
     const int lo = blk * per, hi = (lo + per < P) ? lo + per : P;
     float s = 0.f;
-    for (int p = lo + threadIdx.x; p < hi; p += 256) s += row[p];
+    if ((P & 3) == 0 && (((size_t)row) & 15) == 0) {        // 16 bytes per lane, four loads in flight
+        float s1 = 0.f, s2 = 0.f, s3 = 0.f;
+        int p = lo + 4 * threadIdx.x;
+        for (; p + 3 * 1024 < hi; p += 4 * 1024) {
+            const float4 a = ld4(row + p), b = ld4(row + p + 1024), cc = ld4(row + p + 2048), d = ld4(row + p + 3072);
+            s += (a.x + a.y) + (a.z + a.w); s1 += (b.x + b.y) + (b.z + b.w); s2 += (cc.x + cc.y) + (cc.z + cc.w); s3 += (d.x + d.y) + (d.z + d.w);
+        }
+        for (; p < hi; p += 1024) { const float4 a = ld4(row + p); s += (a.x + a.y) + (a.z + a.w); }
+        s = (s + s1) + (s2 + s3);
+    } else {
+        for (int p = lo + threadIdx.x; p < hi; p += 256) s += row[p];
+    }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
     __shared__ float wsum[4];
@@ -278,6 +302,108 @@ __global__ void __launch_bounds__(256) ln_wgrad_kernel(const float* __restrict__
     __syncthreads();
     if (threadIdx.x < 2)
         partial[(((size_t)img * nblk + blk) * 2 + threadIdx.x) * C + c] = (red[threadIdx.x][0] + red[threadIdx.x][1]) + (red[threadIdx.x][2] + red[threadIdx.x][3]);
+}
+
+// Register-resident fused form (C = CPL * KS <= 128; the layout of layernorm2d_reg_kernel, rf_pointwise.hip): a lane keeps its
+// CPL channels of x AND dy for its 4 pixels, so x and dy are read ONCE and dx written once, and the per-channel sums of
+// dgamma / dbeta accumulate in registers over the workgroup's pixel chunks -- one butterfly + LDS reduction per workgroup at
+// the end (the per-pixel kernel above walks the channels four times with one dependent scalar load in flight, and the weight
+// pass re-reads x and dy once more: 0.18 of HBM).   partial[((img * nblk + blk) * 2 + {0,1}) * C + c], as ln_wgrad_kernel.
+// `res` (may be null): dx = res + (LayerNorm adjoint); res may be a strided view (res_bstride) -- the residual branch of
+// TransformerBlock without a separate add pass.
+template <int CPL, int KS>
+__global__ void __launch_bounds__(256) ln_bwd_reg_kernel(const float* __restrict__ x, const float* __restrict__ dy, const float* __restrict__ gamma,
+                                                         const float* __restrict__ res, int64_t res_bstride, float* __restrict__ dx,
+                                                         float* __restrict__ partial, int C, int P, float eps, int accumulate_dx) {
+    constexpr int G = 64 / KS;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int j = lane % G, ks = lane / G;
+    const size_t img = blockIdx.y;
+    const float* xb = x + img * (size_t)C * P;
+    const float* db = dy + img * (size_t)C * P;
+    const float* rb = res ? res + img * (size_t)res_bstride : nullptr;
+    float* ob = dx + img * (size_t)C * P;
+    const int ngroups = P / 4, per_wg = 4 * G;
+    float gam[CPL], ag[CPL], ab[CPL];
+#pragma unroll
+    for (int s = 0; s < CPL; ++s) { gam[s] = gamma[ks + KS * s]; ag[s] = 0.f; ab[s] = 0.f; }
+    const float invC = 1.0f / (float)C;
+    for (int g0 = blockIdx.x * per_wg; g0 < ngroups; g0 += gridDim.x * per_wg) {
+        const int gi = g0 + wave * G + j;
+        const bool ok = gi < ngroups;
+        const size_t off = (size_t)(ok ? gi : 0) * 4;
+        float4 xv[CPL], dv[CPL];
+#pragma unroll
+        for (int s = 0; s < CPL; ++s) {
+            xv[s] = *reinterpret_cast<const float4*>(xb + (size_t)(ks + KS * s) * P + off);
+            dv[s] = *reinterpret_cast<const float4*>(db + (size_t)(ks + KS * s) * P + off);
+        }
+        float mu[4] = {0.f, 0.f, 0.f, 0.f}, var[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int s = 0; s < CPL; ++s) { mu[0] += xv[s].x; mu[1] += xv[s].y; mu[2] += xv[s].z; mu[3] += xv[s].w; }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+#pragma unroll
+            for (int o = G; o < 64; o <<= 1) mu[q] += __shfl_xor(mu[q], o);
+            mu[q] *= invC;
+        }
+#pragma unroll
+        for (int s = 0; s < CPL; ++s) {
+            xv[s].x -= mu[0]; xv[s].y -= mu[1]; xv[s].z -= mu[2]; xv[s].w -= mu[3];
+            var[0] = fmaf(xv[s].x, xv[s].x, var[0]); var[1] = fmaf(xv[s].y, xv[s].y, var[1]);
+            var[2] = fmaf(xv[s].z, xv[s].z, var[2]); var[3] = fmaf(xv[s].w, xv[s].w, var[3]);
+        }
+        float rstd[4], s1[4] = {0.f, 0.f, 0.f, 0.f}, s2[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+#pragma unroll
+            for (int o = G; o < 64; o <<= 1) var[q] += __shfl_xor(var[q], o);
+            rstd[q] = 1.0f / sqrtf(var[q] * invC + eps);
+        }
+        const float m = ok ? 1.0f : 0.f;              // lanes past the end contribute nothing to the channel sums
+#pragma unroll
+        for (int s = 0; s < CPL; ++s) {
+            // xhat in place; channel sums of dy xhat and dy; g = dy gamma
+            xv[s].x *= rstd[0]; xv[s].y *= rstd[1]; xv[s].z *= rstd[2]; xv[s].w *= rstd[3];
+            ag[s] += m * (fmaf(dv[s].x, xv[s].x, fmaf(dv[s].y, xv[s].y, fmaf(dv[s].z, xv[s].z, dv[s].w * xv[s].w))));
+            ab[s] += m * ((dv[s].x + dv[s].y) + (dv[s].z + dv[s].w));
+            dv[s].x *= gam[s]; dv[s].y *= gam[s]; dv[s].z *= gam[s]; dv[s].w *= gam[s];
+            s1[0] += dv[s].x; s1[1] += dv[s].y; s1[2] += dv[s].z; s1[3] += dv[s].w;
+            s2[0] = fmaf(dv[s].x, xv[s].x, s2[0]); s2[1] = fmaf(dv[s].y, xv[s].y, s2[1]);
+            s2[2] = fmaf(dv[s].z, xv[s].z, s2[2]); s2[3] = fmaf(dv[s].w, xv[s].w, s2[3]);
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+#pragma unroll
+            for (int o = G; o < 64; o <<= 1) { s1[q] += __shfl_xor(s1[q], o); s2[q] += __shfl_xor(s2[q], o); }
+            s1[q] *= invC; s2[q] *= invC;
+        }
+        if (ok) {
+#pragma unroll
+            for (int s = 0; s < CPL; ++s) {
+                float4 v;
+                v.x = rstd[0] * (dv[s].x - s1[0] - xv[s].x * s2[0]); v.y = rstd[1] * (dv[s].y - s1[1] - xv[s].y * s2[1]);
+                v.z = rstd[2] * (dv[s].z - s1[2] - xv[s].z * s2[2]); v.w = rstd[3] * (dv[s].w - s1[3] - xv[s].w * s2[3]);
+                float* o = ob + (size_t)(ks + KS * s) * P + off;
+                if (rb) { const float4 r = *reinterpret_cast<const float4*>(rb + (size_t)(ks + KS * s) * P + off); v.x += r.x; v.y += r.y; v.z += r.z; v.w += r.w; }
+                if (accumulate_dx) { const float4 r = *reinterpret_cast<const float4*>(o); v.x += r.x; v.y += r.y; v.z += r.z; v.w += r.w; }
+                *reinterpret_cast<float4*>(o) = v;
+            }
+        }
+    }
+    // channel sums: over the G pixel-group lanes of a slice (butterfly), then over the four waves in a fixed order
+    __shared__ float red[4][2][CPL * KS];
+#pragma unroll
+    for (int s = 0; s < CPL; ++s) {
+#pragma unroll
+        for (int o = 1; o < G; o <<= 1) { ag[s] += __shfl_xor(ag[s], o); ab[s] += __shfl_xor(ab[s], o); }
+        if (j == 0) { red[wave][0][ks + KS * s] = ag[s]; red[wave][1][ks + KS * s] = ab[s]; }
+    }
+    __syncthreads();
+    for (int e = threadIdx.x; e < 2 * C; e += 256) {
+        const int k = e / C, c = e % C;
+        partial[((img * gridDim.x + blockIdx.x) * 2 + k) * C + c] = (red[0][k][c] + red[1][k][c]) + (red[2][k][c] + red[3][k][c]);
+    }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -367,16 +493,38 @@ __device__ __forceinline__ float gelu_grad(float v) {      // d/dv [ v Phi(v) ] 
     return cdf + v * 0.39894228040143267794f * expf(-0.5f * v * v);
 }
 // mode 0: out = a + b;  1: out = dy * gelu'(x) (a = dy, b = x);  2: out = dy * (y > 0 ? 1 : slope) (a = dy, b = y);
-// 3: out = gelu(a) (exact erf);  4: out += a
+// 3: out = gelu(a) (exact erf);  4: out += a;  5: out = a
+__device__ __forceinline__ float ewise_op(float a, float b, float o, int mode, float slope) {
+    if (mode == 0) return a + b;
+    if (mode == 1) return a * gelu_grad(b);
+    if (mode == 2) return a * (b > 0.f ? 1.0f : slope);
+    if (mode == 3) return 0.5f * a * (1.0f + erff(a * 0.70710678118654752440f));
+    if (mode == 5) return a;
+    return o + a;
+}
+// VEC = 4: 16 bytes per lane and access (n % 4 == 0, 16-byte aligned operands); VEC = 1: any n
+template <int VEC>
 __global__ void __launch_bounds__(256) ewise_kernel(const float* __restrict__ a, const float* __restrict__ b, float* __restrict__ out, size_t n, int mode, float slope) {
-    for (size_t i = blockIdx.x * 256ull + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
-        float v;
-        if (mode == 0) v = a[i] + b[i];
-        else if (mode == 1) v = a[i] * gelu_grad(b[i]);
-        else if (mode == 2) v = a[i] * (b[i] > 0.f ? 1.0f : slope);
-        else if (mode == 3) v = 0.5f * a[i] * (1.0f + erff(a[i] * 0.70710678118654752440f));
-        else v = out[i] + a[i];
-        out[i] = v;
+    const bool need_b = mode <= 2, need_o = mode == 4;
+    for (size_t i = (blockIdx.x * 256ull + threadIdx.x) * VEC; i < n; i += (size_t)gridDim.x * 256 * VEC) {
+        if constexpr (VEC == 4) {
+            const float4 av = *reinterpret_cast<const float4*>(a + i);
+            const float4 bv = need_b ? *reinterpret_cast<const float4*>(b + i) : make_float4(0.f, 0.f, 0.f, 0.f);
+            const float4 ov = need_o ? *reinterpret_cast<const float4*>(out + i) : make_float4(0.f, 0.f, 0.f, 0.f);
+            *reinterpret_cast<float4*>(out + i) = make_float4(ewise_op(av.x, bv.x, ov.x, mode, slope), ewise_op(av.y, bv.y, ov.y, mode, slope),
+                                                              ewise_op(av.z, bv.z, ov.z, mode, slope), ewise_op(av.w, bv.w, ov.w, mode, slope));
+        } else {
+            out[i] = ewise_op(a[i], need_b ? b[i] : 0.f, need_o ? out[i] : 0.f, mode, slope);
+        }
+    }
+}
+
+// [B][2C][P] -> the two channel halves as contiguous tensors [B][C][P] (one pass; replaces 2 B device-to-device copies)
+__global__ void __launch_bounds__(256) split_halves_kernel(const float4* __restrict__ src, float4* __restrict__ a, float4* __restrict__ b, size_t half4, size_t total4) {
+    for (size_t i = blockIdx.x * 256ull + threadIdx.x; i < total4; i += (size_t)gridDim.x * 256) {
+        const size_t img = i / (2 * half4), r = i - img * 2 * half4;
+        const float4 v = src[i];
+        if (r < half4) a[img * half4 + r] = v; else b[img * half4 + (r - half4)] = v;
     }
 }
 
@@ -445,9 +593,20 @@ static void gram2_slabs(int B, int P, int tiles, int* slab_px, int* per_image) {
     *per_image = (P + px - 1) / px;
 }
 
+// A tiles per workgroup of the single-tap form: all of Ca when that is at most 6 tiles, else the divisor that leaves fewest groups
+static int gram2_na(int Ca, int ntap) {
+    if (ntap != 1) return 1;
+    const int nt = cdiv(Ca, 16);
+    if (nt <= 4 || nt == 6) return nt;
+    if (nt % 6 == 0) return 6;
+    if (nt % 4 == 0) return 4;
+    if (nt % 3 == 0) return 3;
+    return nt % 2 == 0 ? 2 : 1;
+}
+
 size_t gram2_partial_floats(int B, int Ca, int Cb, int h, int w, int ntap) {
     int px, per;
-    gram2_slabs(B, h * w, cdiv(Ca, 16) * cdiv(Cb, ntap == 1 ? 64 : 16), &px, &per);
+    gram2_slabs(B, h * w, cdiv(Ca, 16 * gram2_na(Ca, ntap)) * cdiv(Cb, ntap == 1 ? 64 : 16), &px, &per);
     return (size_t)B * per * ntap * Ca * Cb;
 }
 
@@ -460,11 +619,17 @@ int launch_gram2(const float* a, int64_t a_bstride, int Ca, const float* b, int6
     RF_CHECK_ARG(ntap == 1 || ntap == 9, "gram2: ntap must be 1 or 9");
     RF_CHECK_ARG(ntap == 9 || sx == 0, "gram2: the single-tap form shifts rows only (sx = %d)", sx);
     Gram2Args g{a, a_bstride, Ca, b, b_bstride, Cb, partial, B, h, w, sy, sx, 0, 0};
-    gram2_slabs(B, h * w, cdiv(Ca, 16) * cdiv(Cb, ntap == 1 ? 64 : 16), &g.slab_px, &g.slabs_per_image);
+    const int na = gram2_na(Ca, ntap);
+    gram2_slabs(B, h * w, cdiv(Ca, 16 * na) * cdiv(Cb, ntap == 1 ? 64 : 16), &g.slab_px, &g.slabs_per_image);
     const int nslab = B * g.slabs_per_image;
     ProfScope prof(st, ntap == 1 ? "gram2_kernel<1>" : "gram2_kernel<9>", 2.0 * ntap * Ca * Cb * (double)B * h * w, 4.0 * (double)B * h * w * (Ca + Cb));
-    if (ntap == 1) gram2_kernel<1><<<dim3((unsigned)nslab, (unsigned)cdiv(Ca, 16), (unsigned)cdiv(Cb, 64)), 256, 0, st>>>(g);
-    else gram2_kernel<9><<<dim3((unsigned)nslab, (unsigned)cdiv(Ca, 16), (unsigned)cdiv(Cb, 16)), 256, 0, st>>>(g);
+    const dim3 grid1((unsigned)nslab, (unsigned)cdiv(Ca, 16 * na), (unsigned)cdiv(Cb, 64));
+    if (ntap == 9) gram2_kernel<9, 1><<<dim3((unsigned)nslab, (unsigned)cdiv(Ca, 16), (unsigned)cdiv(Cb, 16)), 256, 0, st>>>(g);
+    else if (na == 6) gram2_kernel<1, 6><<<grid1, 256, 0, st>>>(g);
+    else if (na == 4) gram2_kernel<1, 4><<<grid1, 256, 0, st>>>(g);
+    else if (na == 3) gram2_kernel<1, 3><<<grid1, 256, 0, st>>>(g);
+    else if (na == 2) gram2_kernel<1, 2><<<grid1, 256, 0, st>>>(g);
+    else gram2_kernel<1, 1><<<grid1, 256, 0, st>>>(g);
     const size_t n = (size_t)ntap * Ca * Cb;
     reduce_gram2_kernel<<<dim3((unsigned)red_grid(n), per_image ? (unsigned)B : 1u), 256, 0, st>>>(
         partial, out, per_image ? g.slabs_per_image : nslab, ntap, Ca, Cb, ld, out_istride, accumulate);
@@ -477,7 +642,7 @@ int launch_reduce_rows(const float* partial, float* out, int nrows, size_t n, in
     return check_launch("reduce_rows");
 }
 
-int chan_sum_nblk(int P) { int n = P / 4096; return n < 1 ? 1 : n > 64 ? 64 : n; }
+int chan_sum_nblk(int P) { int n = P / 16384; return n < 1 ? 1 : n > 16 ? 16 : n; }
 
 int launch_chan_sum(const float* x, int64_t bstride, float* out, float* partial, int B, int C, int P, int accumulate, hipStream_t st) {
     const int nblk = chan_sum_nblk(P);
@@ -490,18 +655,58 @@ int launch_chan_sum(const float* x, int64_t bstride, float* out, float* partial,
 // partial: ln_bwd_partial_floats floats = per-pixel statistics + the per-block sums.  dx must not alias dy (the weight pass
 // reads dy after dx has been written).
 static int ln_nblk(int P) { int n = P / 4096; return n < 1 ? 1 : n > 64 ? 64 : n; }
+static int ln_reg_nblk(int B, int P, int per_wg) {
+    int gx = cdiv(P / 4, per_wg);
+    const int cap = cdiv(256 * 4, B);              // about four workgroups per CU over the batch: each loops over its pixel chunks
+    return gx > cap ? cap : gx;
+}
+template <int CPL, int KS>
+static int launch_ln_bwd_reg(const float* x, const float* dy, const float* gamma, const float* res, int64_t res_bstride, float* dx, float* dgb,
+                             float* partial, int B, int C, int P, float eps, int accumulate_dx, int accumulate_w, hipStream_t st) {
+    const int nblk = ln_reg_nblk(B, P, 4 * (64 / KS));
+    ln_bwd_reg_kernel<CPL, KS><<<dim3((unsigned)nblk, (unsigned)B), 256, 0, st>>>(x, dy, gamma, res, res_bstride, dx, partial, C, P, eps, accumulate_dx);
+    reduce_partials_kernel<<<red_grid(2 * C), 256, 0, st>>>(partial, dgb, B * nblk, (size_t)2 * C, accumulate_w);
+    return check_launch("ln_bwd");
+}
 int launch_ln_bwd(const float* x, const float* dy, const float* gamma, float* dx, float* dgb, float* partial,
-                  int B, int C, int P, float eps, int accumulate_dx, int accumulate_w, hipStream_t st) {
+                  int B, int C, int P, float eps, int accumulate_dx, int accumulate_w, hipStream_t st, const float* res, int64_t res_bstride) {
+    ProfScope prof(st, "ln_bwd", 14.0 * B * C * P, (res ? 16.0 : 12.0) * B * C * P);
+    if ((P & 3) == 0 && aligned16(x) && aligned16(dy) && aligned16(dx) && (!res || (aligned16(res) && res_bstride % 4 == 0)) && B <= 65535) {
+#define RF_LN_BWD(CPL, KS) return launch_ln_bwd_reg<CPL, KS>(x, dy, gamma, res, res_bstride, dx, dgb, partial, B, C, P, eps, accumulate_dx, accumulate_w, st)
+        switch (C) {
+            case 16: RF_LN_BWD(4, 4);
+            case 32: RF_LN_BWD(8, 4);
+            case 48: RF_LN_BWD(12, 4);
+            case 64: RF_LN_BWD(16, 4);
+            case 96: RF_LN_BWD(12, 8);
+            case 128: RF_LN_BWD(16, 8);
+            case 192: RF_LN_BWD(12, 16);
+            case 256: RF_LN_BWD(16, 16);
+            case 384: RF_LN_BWD(12, 32);
+            case 512: RF_LN_BWD(16, 32);
+            default: break;
+        }
+#undef RF_LN_BWD
+    }
+    // generic channel counts (level 3: C = 256 ...): per-pixel kernel + weight pass; the residual is added by a separate pass
     const int nblk = ln_nblk(P);
     float* stats = partial;
     float* sums = partial + align_up((size_t)B * 2 * P, 64);
-    ProfScope prof(st, "ln_bwd(2 kernels)", 14.0 * B * C * P, 20.0 * B * C * P);
+    if (res) {
+        RF_CHECK_ARG(!accumulate_dx && res_bstride == (int64_t)C * P, "ln_bwd: the generic path takes a contiguous residual");
+        if (int rc = launch_ewise(res, nullptr, dx, (size_t)B * C * P, 5, 0.f, st)) return rc;       // dx = res, then accumulate
+        accumulate_dx = 1;
+    }
     ln_bwd_kernel<<<dim3((unsigned)cdiv(P, 256), (unsigned)B), 256, 0, st>>>(x, dy, gamma, dx, stats, C, P, eps, accumulate_dx);
     ln_wgrad_kernel<<<dim3((unsigned)nblk, (unsigned)C, (unsigned)B), 256, 0, st>>>(x, dy, stats, sums, C, P, nblk);
     reduce_partials_kernel<<<red_grid(2 * C), 256, 0, st>>>(sums, dgb, B * nblk, (size_t)2 * C, accumulate_w);
     return check_launch("ln_bwd");
 }
-size_t ln_bwd_partial_floats(int B, int C, int P) { return align_up((size_t)B * 2 * P, 64) + (size_t)B * ln_nblk(P) * 2 * C; }
+size_t ln_bwd_partial_floats(int B, int C, int P) {
+    const size_t generic = align_up((size_t)B * 2 * P, 64) + (size_t)B * ln_nblk(P) * 2 * C;
+    const size_t reg = (size_t)B * 1024 * 2 * C;
+    return generic > reg ? generic : reg;
+}
 
 int dw_wgrad_nblk(int P) { int n = P / 8192; return n < 1 ? 1 : n > 32 ? 32 : n; }
 size_t dw_wgrad_partial_floats(int B, int C, int P) { return (size_t)B * dw_wgrad_nblk(P) * C * 10; }
@@ -519,8 +724,18 @@ int launch_dw_wgrad(const float* x, const float* dy, float* dw, float* db, float
 }
 
 int launch_ewise(const float* a, const float* b, float* out, size_t n, int mode, float slope, hipStream_t st) {
-    ewise_kernel<<<grid1d(n), 256, 0, st>>>(a, b, out, n, mode, slope);
+    ProfScope prof(st, "ewise_kernel", 0.0, (mode == 3 || mode == 5 ? 8.0 : 12.0) * n);
+    if (n % 4 == 0 && aligned16(a) && aligned16(out) && (!b || aligned16(b))) ewise_kernel<4><<<grid1d(n / 4), 256, 0, st>>>(a, b, out, n, mode, slope);
+    else ewise_kernel<1><<<grid1d(n), 256, 0, st>>>(a, b, out, n, mode, slope);
     return check_launch("ewise");
+}
+
+int launch_split_halves(const float* src, float* a, float* b, int B, int C, int P, hipStream_t st) {
+    RF_CHECK_ARG(((size_t)C * P) % 4 == 0 && aligned16(src) && aligned16(a) && aligned16(b), "split_halves: C * P must be a multiple of 4, buffers 16-byte aligned");
+    const size_t half4 = (size_t)C * P / 4, total4 = 2 * half4 * B;
+    ProfScope prof(st, "split_halves_kernel", 0.0, 32.0 * half4 * B);
+    split_halves_kernel<<<grid1d(total4), 256, 0, st>>>(reinterpret_cast<const float4*>(src), reinterpret_cast<float4*>(a), reinterpret_cast<float4*>(b), half4, total4);
+    return check_launch("split_halves");
 }
 
 int launch_flip3x3(const float* w, float* out, int Cout, int Cin, int dense, hipStream_t st) {

@@ -414,10 +414,7 @@ int stage_backward(const Ctx& c, int i, int lvl, float* dout, float* din, int H,
     RF_TRY(b_conv1x1_dw(c, tB, C, s.trans, C, c.G(pre + "channel_reduce.weight"), 2 * C, C, nullptr, hh, ww));
     RF_TRY(b_conv1x1_dx(c, tB, C, P(h, pre + "channel_reduce.weight"), 2 * C, tC, Pn));               // tC = [dxs ; dtrans] per image
     // the two halves as contiguous tensors: tA = dxs, tD = dtrans
-    for (int b = 0; b < c.B; ++b) {
-        RF_TRY(check_hip(hipMemcpyAsync(tA + (size_t)b * C * Pn, tC + (size_t)b * 2 * C * Pn, (size_t)C * Pn * 4, hipMemcpyDeviceToDevice, c.st), "split"));
-        RF_TRY(check_hip(hipMemcpyAsync(tD + (size_t)b * C * Pn, tC + ((size_t)b * 2 + 1) * C * Pn, (size_t)C * Pn * 4, hipMemcpyDeviceToDevice, c.st), "split"));
-    }
+    RF_TRY(launch_split_halves(tC, tA, tD, c.B, C, Pn, c.st));
     if (cfg.variant == RF_VARIANT_FLCA) {
         const std::string f = pre + "FLCA.";
         const char* names[10] = {"alpha", "beta", "gamma", "low_attn.0.weight", "high_attn.0.weight", "chroma_attn.0.weight",
@@ -582,10 +579,7 @@ int rf_train_step(rf_handle* h, const float* in, const float* gt, float* grads, 
         RF_TRY(b_conv1x1_dw(c, gb, C, p.up[i - 1], C, c.G(r + ".weight"), 2 * C, 0, c.G(r + ".bias"), hh, ww));
         RF_TRY(b_conv1x1_dw(c, gb, C, p.st[lvl + 1].out, C, c.G(r + ".weight"), 2 * C, C, nullptr, hh, ww));
         RF_TRY(b_conv1x1_dx(c, gb, C, P(h, r + ".weight"), 2 * C, p.tC, Pn));                 // tC = [dup ; dskip]
-        for (int b = 0; b < B; ++b) {
-            RF_TRY(check_hip(hipMemcpyAsync(p.tA + (size_t)b * C * Pn, p.tC + (size_t)b * 2 * C * Pn, (size_t)C * Pn * 4, hipMemcpyDeviceToDevice, st), "split"));
-            RF_TRY(check_hip(hipMemcpyAsync(p.dskip[lvl] + (size_t)b * C * Pn, p.tC + ((size_t)b * 2 + 1) * C * Pn, (size_t)C * Pn * 4, hipMemcpyDeviceToDevice, st), "split"));
-        }
+        RF_TRY(launch_split_halves(p.tC, p.tA, p.dskip[lvl], B, C, Pn, st));
         // ConvTranspose2d(2C -> C): dX = conv1x1(unshuffle(dup), W as [2C][4C]);  dW = gram2(x, unshuffle(dup));  db = channel sums of dup
         RF_TRY(launch_chan_sum(p.tA, (int64_t)C * Pn, c.G(u + ".bias"), p.part, B, C, Pn, 1, st));
         RF_TRY(launch_pixel_unshuffle2(p.tA, p.tB, B, C, hh / 2, ww / 2, st));                 // [B, 4C, hh/2, ww/2]
