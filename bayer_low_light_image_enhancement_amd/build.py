@@ -20,7 +20,7 @@ LIB = os.path.join(CSRC, "librawformer_hip.so")
 # RF_NO_FUSE / RF_NO_UPCAT / RF_NO_B3 (force the op-by-op schedule / the f32 MFMA GEMMs) so tests can compare the fused kernels with the un-fused chain.
 # The shipped library has no such switch.  Selected with RF_LIB_PATH (see _lib.py).
 DIAG_LIB = os.path.join(CSRC, "librawformer_hip_diag.so")
-DIAG_SOURCES = ["rf_block.hip", "rf_model.hip", "rf_gemm1x1.hip"]
+DIAG_SOURCES = ["rf_block.hip", "rf_model.hip", "rf_gemm1x1.hip", "rf_fused.hip"]
 SOURCES = ["rf_api.hip", "rf_model.hip", "rf_pack.hip", "rf_pointwise.hip", "rf_gemm1x1.hip",
            "rf_conv3x3.hip", "rf_attn.hip", "rf_flca.hip", "rf_fused.hip", "rf_block.hip", "rf_harness.hip", "rf_tokattn.hip", "rf_wfb.hip", "rf_upcat.hip", "rf_fft.hip", "rf_ffab.hip", "rf_truecolor.hip", "rf_train.hip", "rf_trainstep.hip"]
 # every header a source may include: ONE list for the product and the diagnostic objects (a stale *_diag.o linked with fresh

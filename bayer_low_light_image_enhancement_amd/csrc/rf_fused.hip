@@ -21,6 +21,7 @@
 // Weights of the current part are staged in LDS in MFMA lane order.  All cross-workgroup
 // reductions go through fixed-order partials (bitwise reproducible).
 #include <cstdio>
+#include <cstdlib>
 #include "rf_common.h"
 
 namespace rf {
@@ -469,13 +470,218 @@ __global__ void __launch_bounds__(256, 2) ffn_fused_kernel(FfnArgs a) {
     STAMP_FLUSH;
 }
 
+// ================================================================================================
+// The same FFN for C = 48 and C = 64 (level 0 of RawFormer-B / -L, level 1 of RawFormer-S) on EIGHT-wave workgroups, one per CU.
+// Two steps of b3 pieces per wave (the C = 32 kernel) would need 192 registers at C = 64; here the 108 halo'd pixel groups are
+// spread over eight waves -- 14 each, ONE phase-A step and 96 registers of pieces per wave -- and phase B splits the K dimension
+// of the second GEMM instead of the pixels: waves 0-3 and 4-7 own the same four output rows, wave half `hf` runs the
+// depthwise stencil + GELU and the MFMAs of k-steps [4 hf, 4 hf + 4) of every part (no stencil is evaluated twice), and the two
+// partial accumulator sets are added through LDS once per tile (64 KB = the `mid` planes, free by then).  K of the first GEMM
+// is padded to a multiple of 32 with zero pieces (C = 48: the packed weight is zero-padded the same way).
+// LDS at C = 64: 64 KB mid / reduction + 48 KB W1 (b3) + 32 KB W2 + 6 KB of vectors = 150 KB.
+// ================================================================================================
+namespace fused8 {
+constexpr int GPW = 14;                 // pixel groups per wave in phase A (8 x 14 = 112 >= 108)
+}
+
+__device__ __forceinline__ GroupGeom group_geom8(int wave, int j, int y0, int x0, int h, int w) {
+    using namespace fused;
+    GroupGeom g;
+    const int gi = wave * fused8::GPW + j;
+    const bool in_step = j < fused8::GPW && gi < NG;
+    const int row = gi / (HC / 4), cg = gi % (HC / 4);
+    const int y = y0 - 1 + row, x = x0 - 4 + 4 * cg;
+    g.valid = in_step && y >= 0 && y < h && x >= 0 && x < w;
+    g.lds_off = in_step ? row * HC + 4 * cg : -1;
+    g.goff = g.valid ? y * w + x : 0;
+    return g;
+}
+
+// input of one step, K padded to KP: lane (j, kq) holds channels 32 kb + 8 kq + i; channels >= C are zeros (loaded from a
+// clamped address, selected away: the loads stay branch-free)
+template <int C, int KP>
+__device__ __forceinline__ void load_step_b3p(const float* __restrict__ xb, int P, int kq, const GroupGeom& g, float4 (&xh)[KP / 4]) {
+#pragma unroll
+    for (int s = 0; s < KP / 4; ++s) {
+        const int ch = 32 * (s >> 3) + 8 * kq + (s & 7);
+        xh[s] = *reinterpret_cast<const float4*>(xb + (size_t)(ch < C ? ch : 0) * P + (unsigned)g.goff);
+    }
+}
+
+template <int C, int KP>
+__device__ __forceinline__ void ln_step_b3p(int kq, const float* __restrict__ gam_l, const float* __restrict__ bet_l, float eps, float4 (&xh)[KP / 4]) {
+    constexpr int NS = KP / 4;
+    float sum[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int s = 0; s < NS; ++s) {
+        const bool ok = 32 * (s >> 3) + 8 * kq + (s & 7) < C;
+        if (!ok) xh[s] = make_float4(0.f, 0.f, 0.f, 0.f);
+        sum[0] += xh[s].x; sum[1] += xh[s].y; sum[2] += xh[s].z; sum[3] += xh[s].w;
+    }
+    float mu[4], var[4] = {0.f, 0.f, 0.f, 0.f}, rstd[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        sum[q] += __shfl_xor(sum[q], 16);
+        sum[q] += __shfl_xor(sum[q], 32);
+        mu[q] = sum[q] * (1.0f / C);
+    }
+#pragma unroll
+    for (int s = 0; s < NS; ++s) {
+        const float m = (32 * (s >> 3) + 8 * kq + (s & 7) < C) ? 1.0f : 0.f;
+        const float d0 = m * (xh[s].x - mu[0]), d1 = m * (xh[s].y - mu[1]), d2 = m * (xh[s].z - mu[2]), d3 = m * (xh[s].w - mu[3]);
+        var[0] = fmaf(d0, d0, var[0]); var[1] = fmaf(d1, d1, var[1]);
+        var[2] = fmaf(d2, d2, var[2]); var[3] = fmaf(d3, d3, var[3]);
+    }
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        var[q] += __shfl_xor(var[q], 16);
+        var[q] += __shfl_xor(var[q], 32);
+        rstd[q] = 1.0f / sqrtf(var[q] * (1.0f / C) + eps);
+    }
+#pragma unroll
+    for (int s = 0; s < NS; ++s) {
+        const int ch = 32 * (s >> 3) + 8 * kq + (s & 7);
+        const bool ok = ch < C;
+        const float gk = gam_l[ok ? ch : 0], bk = bet_l[ok ? ch : 0];
+        xh[s].x = ok ? fmaf((xh[s].x - mu[0]) * rstd[0], gk, bk) : 0.f;
+        xh[s].y = ok ? fmaf((xh[s].y - mu[1]) * rstd[1], gk, bk) : 0.f;
+        xh[s].z = ok ? fmaf((xh[s].z - mu[2]) * rstd[2], gk, bk) : 0.f;
+        xh[s].w = ok ? fmaf((xh[s].w - mu[3]) * rstd[3], gk, bk) : 0.f;
+    }
+}
+
+template <int C>
+__global__ void __launch_bounds__(512, 1) ffn_fused8_kernel(FfnArgs a) {
+    using namespace fused;
+    constexpr int KP = (C + 31) / 32 * 32; // K of the first GEMM, padded
+    constexpr int NT1 = 2 * C / 16;      // output tiles of the first GEMM (hidden)
+    constexpr int NTO = C / 16;          // output tiles of the second GEMM
+    constexpr int NPART = 2 * C / PART;  // parts of 32 hidden channels
+    constexpr int PS = 448;
+    constexpr int MIDF = (PART * PS + 8 > NTO * 4 * 256 * 4) ? PART * PS + 8 : NTO * 4 * 256 * 4;      // planes, or the K-split reduction
+    __shared__ __attribute__((aligned(16))) float mid[MIDF];
+    __shared__ __attribute__((aligned(16))) u32x4 w1_l[(KP / 32) * NT1 * 192];
+    __shared__ __attribute__((aligned(16))) float w2_l[(2 * C / 4) * NTO * 64];
+    __shared__ float wd_l[2 * C * 9], bd_l[2 * C], b1_l[2 * C], b2_l[C], gam_l[C], bet_l[C];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int row = wave & 3, hf = wave >> 2;
+    const int b = blockIdx.y;
+    const int h = a.h, w = a.w, P = h * w;
+    const float* xb = a.x + (size_t)b * C * P;
+    float* ob = a.out + (size_t)b * C * P;
+
+    for (int i = tid; i < (KP / 32) * NT1 * 192; i += 512) w1_l[i] = reinterpret_cast<const u32x4*>(a.w1p)[i];
+    for (int i = tid; i < (2 * C / 4) * NTO * 16; i += 512) *reinterpret_cast<float4*>(w2_l + i * 4) = *reinterpret_cast<const float4*>(a.w2p + i * 4);
+    for (int i = tid; i < 2 * C * 9; i += 512) wd_l[i] = a.wd[i];
+    for (int i = tid; i < 2 * C; i += 512) { bd_l[i] = a.bd[i]; b1_l[i] = a.b1[i]; }
+    for (int i = tid; i < C; i += 512) { gam_l[i] = a.ln_w[i]; bet_l[i] = a.ln_b[i]; b2_l[i] = a.b2[i]; }
+    __syncthreads();
+
+    const int tiles_y = a.ntiles / a.tiles_x;
+    const int per = (a.ntiles + (int)gridDim.x - 1) / (int)gridDim.x;
+    const int t_begin = blockIdx.x * per, t_end = (t_begin + per < a.ntiles) ? t_begin + per : a.ntiles;
+    const int j0 = lane & 15, kq0 = lane >> 4, lane0 = lane;
+    for (int tile = t_begin; tile < t_end; ++tile) {
+        const int tx = tile / tiles_y, ty = tile % tiles_y;
+        const int x0 = tx * TW, y0 = ty * TH;
+        // the lane coordinates are made opaque once per tile: everything derived from them (LDS plane / weight / stencil addresses)
+        // would otherwise be hoisted out of the tile loop into long-lived registers and spilled (112 of them)
+        int j = j0, kq = kq0, lane = lane0;
+        asm volatile("" : "+v"(j), "+v"(kq), "+v"(lane));
+        const GroupGeom gw = group_geom8(wave, j, y0, x0, h, w);
+        u32x4 bp[KP / 32][4][3];
+        {
+            float4 xh[KP / 4];
+            load_step_b3p<C, KP>(xb, P, kq, gw, xh);
+            ln_step_b3p<C, KP>(kq, gam_l, bet_l, 1e-5f, xh);
+            split_step<KP>(xh, bp);
+        }
+        const int yo = y0 + row, xo = x0 + 4 * j;            // this lane's 4 output pixels (both wave halves)
+        const bool live = yo < h && xo < w;
+        const unsigned voff = (unsigned)(4 * kq) * (unsigned)P + (unsigned)(live ? yo * w + xo : 0);
+        f32x4 acc[NTO][4];
+#pragma unroll
+        for (int t = 0; t < NTO; ++t)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) acc[t][q] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+#pragma unroll 1
+        for (int part = 0; part < NPART; ++part) {
+            lds_barrier();                                 // previous phase B (or the previous tile's reduction) is done with mid
+            phase_a_step_b3<KP, NT1>(bp, w1_l + lane, 2 * part, 2 * part + 1, b1_l + part * PART, b1_l + part * PART + 16, mid, PS, kq, gw);
+            lds_barrier();
+            // ---- phase B: this wave half's four k-steps of the part (not unrolled: hoisted stencil loads would spill)
+#pragma unroll 1
+            for (int s4 = 0; s4 < PART / 8; ++s4) {
+                const int s = 4 * hf + s4, hc = 4 * s + kq;
+                float v[4];
+                stencil4_dpp(mid + hc * PS + row * HC + 4 * j + 4, j, wd_l + (part * PART + hc) * 9, bd_l[part * PART + hc], v);
+#pragma unroll
+                for (int q = 0; q < 4; ++q) v[q] = gelu_fast(v[q]);
+#pragma unroll
+                for (int t = 0; t < NTO; ++t) {
+                    const float av = w2_l[((part * (PART / 4) + s) * NTO + t) * 64 + lane];
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) acc[t][q] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, v[q], acc[t][q], 0, 0, 0);
+                }
+            }
+        }
+        // ---- the two K halves: waves 4-7 hand their accumulators to waves 0-3 through LDS (mid is free after the barrier)
+        lds_barrier();
+        float4* red = reinterpret_cast<float4*>(mid);
+        if (hf == 1) {
+#pragma unroll
+            for (int t = 0; t < NTO; ++t)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) red[(t * 4 + q) * 256 + row * 64 + lane] = make_float4(acc[t][q][0], acc[t][q][1], acc[t][q][2], acc[t][q][3]);
+        }
+        float4 resv[NTO * 4];
+        if (hf == 0) {                                     // residual rows, in flight across the barrier
+#pragma unroll
+            for (int t = 0; t < NTO; ++t)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) resv[t * 4 + r] = *reinterpret_cast<const float4*>(xb + (size_t)(16 * t + r) * P + voff);
+        }
+        lds_barrier();
+        if (hf == 0) {
+#pragma unroll
+            for (int t = 0; t < NTO; ++t)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const float4 o = red[(t * 4 + q) * 256 + row * 64 + lane];
+                    acc[t][q][0] += o.x; acc[t][q][1] += o.y; acc[t][q][2] += o.z; acc[t][q][3] += o.w;
+                }
+            if (live) {
+#pragma unroll
+                for (int t = 0; t < NTO; ++t)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int cu = 16 * t + r;
+                        const float bs = b2_l[cu + 4 * kq];
+                        const float4 rv = resv[t * 4 + r];
+                        *reinterpret_cast<float4*>(ob + (size_t)cu * P + voff) =
+                            make_float4(acc[t][0][r] + bs + rv.x, acc[t][1][r] + bs + rv.y, acc[t][2][r] + bs + rv.z, acc[t][3][r] + bs + rv.w);
+                    }
+            }
+        }
+    }
+}
+
+// C = 64 is built and tested (diagnostic twin: RF_FFN8_64=1) but NOT dispatched: measured on MI355X the eight-wave kernel ties the
+// op-by-op chain there (RawFormer-L level 0, 3 M pixels: 1.98 ms against 1.85 ms; RawFormer-S level 1: 0.33 against 0.30 ms) --
+// at 64 channels the kernel is bound by MFMA + VALU issue (they do not overlap on this chip) where the chain is bound by HBM,
+// and both take the same time.  C = 48 (RawFormer-B level 0) gains 8 % of its FFN.
 bool fused_ffn_supported(int C, int hidden, int h, int w) {
-    return C == 32 && hidden == 2 * C && (w % 4 == 0) && ((double)C * h * w * 4.0 < 4.0e9);
+#ifdef RF_DIAG
+    if (C == 64 && getenv("RF_FFN8_64") && hidden == 2 * C && (w % 4 == 0) && ((double)C * h * w * 4.0 < 4.0e9)) return true;
+#endif
+    return (C == 32 || C == 48) && hidden == 2 * C && (w % 4 == 0) && ((double)C * h * w * 4.0 < 4.0e9);
 }
 
 int launch_ffn_fused(const float* x, float* out, const float* ln_w, const float* ln_b, const void* w1p, const float* b1,
                      const float* wd, const float* bd, const float* w2p, const float* b2, int B, int C, int h, int w, hipStream_t st) {
-    RF_CHECK_ARG(fused_ffn_supported(C, 2 * C, h, w) && B <= 65535, "ffn_fused: unsupported shape C=%d %dx%d", C, h, w);
+    RF_CHECK_ARG((C == 32 || C == 48 || C == 64) && w % 4 == 0 && (double)C * h * w * 4.0 < 4.0e9 && B <= 65535, "ffn_fused: unsupported shape C=%d %dx%d", C, h, w);
     RF_CHECK_ARG(aligned16(x) && aligned16(out) && aligned16(w1p), "ffn_fused: buffers must be 16-byte aligned");
     FfnArgs a{x, out, ln_w, ln_b, w1p, b1, wd, bd, w2p, b2, B, h, w, cdiv(w, fused::TW), 0};
     a.ntiles = a.tiles_x * cdiv(h, fused::TH);
@@ -483,6 +689,16 @@ int launch_ffn_fused(const float* x, float* out, const float* ln_w, const float*
     if (wgs > a.ntiles) wgs = a.ntiles;
     const dim3 grid((unsigned)wgs, (unsigned)B);
     const double px = (double)B * h * w;
+    if (C != 32) {
+        // eight-wave form: one workgroup per CU, persistent over the whole batch
+        int wg8 = cdiv(256, B);
+        if (wg8 > a.ntiles) wg8 = a.ntiles;
+        const dim3 grid8((unsigned)wg8, (unsigned)B);
+        ProfScope prof(st, C == 64 ? "ffn_fused8_kernel<64>" : "ffn_fused8_kernel<48>", px * (8.0 * C * C + 36.0 * C), px * 8.0 * C);
+        if (C == 64) ffn_fused8_kernel<64><<<grid8, 512, 0, st>>>(a);
+        else ffn_fused8_kernel<48><<<grid8, 512, 0, st>>>(a);
+        return check_launch("ffn_fused8");
+    }
     ProfScope prof(st, "ffn_fused_kernel<32>", px * (8.0 * C * C + 36.0 * C), px * 8.0 * C);
     ffn_fused_kernel<32><<<grid, 256, 0, st>>>(a);
     return check_launch("ffn_fused");
