@@ -914,6 +914,79 @@ __global__ void __launch_bounds__(256) flca_spatial_bwd_kernel(FlcaBwdArgs a) {
         a.abg_partial[(b * a.nblk + blk) * 3 + threadIdx.x] = (red[threadIdx.x][0] + red[threadIdx.x][1]) + (red[threadIdx.x][2] + red[threadIdx.x][3]);
 }
 
+// Tap sums of the three gate convolutions in ONE pass over ds (they had been three gram2<9> launches whose 16 x 16 tiles held
+// one or two useful B rows: 21 launches and 2.5 ms of the step).  G[c][col] = sum_p ds_k[c][p] * plane_k[p + tap], a contraction over
+// pixels with the TAPS as the B rows: lane (r, kq) of the B operand loads tap r of its plane at the lane's 4 pixels (the guidance
+// planes are 4 x P floats: cache resident), the A operands are 16-byte rows of ds_low / ds_high / ds_chr.  Four accumulator
+// tiles per A tile: low x plane 0, high x plane 1, chroma x plane 2, chroma x plane 3 (columns 0-8 = the 3 x 3 window).
+// partial[(slab * C + c) * 36 + {low 0-8, high 9-17, chroma 18-35}], slabs reduced in order by reduce_partials_kernel.
+__global__ void __launch_bounds__(256) flca_taps_kernel(const float* __restrict__ ds, size_t plane_stride, const float* __restrict__ guide,
+                                                        float* __restrict__ partial, int C, int h, int w, int slab_px, int slabs_per_image) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int r = lane & 15, kq = lane >> 4;
+    const int slab = blockIdx.x, ti = blockIdx.y;
+    const int img = slab / slabs_per_image, sl = slab - img * slabs_per_image;
+    const int P = h * w;
+    const int n_lo = sl * slab_px, n_hi = (n_lo + slab_px < P) ? n_lo + slab_px : P;
+    const int ch = (16 * ti + r < C) ? 16 * ti + r : C - 1;
+    const float* a0 = ds + ((size_t)img * C + ch) * P;                 // ds_low row of this lane's channel (A operand)
+    const float* gpl = guide + (size_t)img * 4 * P;
+    const int dy = r < 9 ? r / 3 - 1 : 0, dx = r < 9 ? r % 3 - 1 : 0;  // this lane's tap (B operand rows 9-15 are zero)
+    f32x4 acc[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) acc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    for (int n0 = n_lo + wave * 16; n0 < n_hi; n0 += 64) {
+        const int nn = n0 + 4 * kq;
+        const bool ok = nn < n_hi;
+        const int n = ok ? nn : n_lo;
+        const float4 al = ld4(a0 + n), ah = ld4(a0 + plane_stride + n), ac = ld4(a0 + 2 * plane_stride + n);
+        const int y = n / w, x = n - y * w, yy = y + dy;
+        const bool rowok = ok && r < 9 && yy >= 0 && yy < h;
+        float bv[4][4];
+#pragma unroll
+        for (int m = 0; m < 4; ++m) {
+            const int xx = x + m + dx;
+            const bool in = rowok && xx >= 0 && xx < w;
+            const size_t off = in ? (size_t)yy * w + xx : 0;
+#pragma unroll
+            for (int pl = 0; pl < 4; ++pl) { const float v = gpl[(size_t)pl * P + off]; bv[pl][m] = in ? v : 0.f; }
+        }
+        const float aL[4] = {ok ? al.x : 0.f, ok ? al.y : 0.f, ok ? al.z : 0.f, ok ? al.w : 0.f};
+        const float aH[4] = {ok ? ah.x : 0.f, ok ? ah.y : 0.f, ok ? ah.z : 0.f, ok ? ah.w : 0.f};
+        const float aC[4] = {ok ? ac.x : 0.f, ok ? ac.y : 0.f, ok ? ac.z : 0.f, ok ? ac.w : 0.f};
+#pragma unroll
+        for (int m = 0; m < 4; ++m) {
+            acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(aL[m], bv[0][m], acc[0], 0, 0, 0);
+            acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(aH[m], bv[1][m], acc[1], 0, 0, 0);
+            acc[2] = __builtin_amdgcn_mfma_f32_16x16x4f32(aC[m], bv[2][m], acc[2], 0, 0, 0);
+            acc[3] = __builtin_amdgcn_mfma_f32_16x16x4f32(aC[m], bv[3][m], acc[3], 0, 0, 0);
+        }
+    }
+    __shared__ float red[4][16][17];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+        __syncthreads();
+#pragma unroll
+        for (int q = 0; q < 4; ++q) red[wave][4 * kq + q][r] = acc[t][q];
+        __syncthreads();
+        const int i = threadIdx.x >> 4, jj = threadIdx.x & 15;
+        const int gi = 16 * ti + i;
+        if (gi < C && jj < 9)
+            partial[((size_t)slab * C + gi) * 36 + 9 * t + jj] = ((red[0][i][jj] + red[1][i][jj]) + red[2][i][jj]) + red[3][i][jj];
+    }
+}
+
+// the 36 tap sums of a channel -> the three weight gradients: low [C][9], high [C][9], chroma [C][2][9]
+__global__ void __launch_bounds__(256) flca_taps_scatter_kernel(const float* __restrict__ sums, float* __restrict__ g_low, float* __restrict__ g_high,
+                                                                float* __restrict__ g_chr, int C) {
+    for (int e = blockIdx.x * 256 + threadIdx.x; e < C * 36; e += gridDim.x * 256) {
+        const int c = e / 36, t = e % 36;
+        if (t < 9) g_low[c * 9 + t] += sums[e];
+        else if (t < 18) g_high[c * 9 + t - 9] += sums[e];
+        else g_chr[c * 18 + t - 18] += sums[e];
+    }
+}
+
 __global__ void __launch_bounds__(256) flca_abg_kernel(const float* __restrict__ partial, int nrec, float* __restrict__ ga, float* __restrict__ gb, float* __restrict__ gg) {
     __shared__ float part[3][256];
     float s[3] = {0.f, 0.f, 0.f};
@@ -937,7 +1010,7 @@ __global__ void __launch_bounds__(256) flca_abg_kernel(const float* __restrict__
 size_t flca_bwd_scratch_floats(int B, int C, int h, int w) {
     const int P = h * w;
     return 3 * (size_t)B * C * P + (size_t)B * cdiv(P, 256) * 3 + (size_t)B * chan_sum_nblk(P) * C + 2 * (size_t)B * C + 256 +
-           gram2_partial_floats(B, C, 2, h, w, 9);
+           gram2_partial_floats(B, C, 2, h, w, 9) + gram2_partial_floats(B, C, 16, h, w, 1) * 3 + (size_t)C * 36 + 64;
 }
 
 // prm / grd: alpha, beta, gamma, low_attn.0.w, high_attn.0.w, chroma_attn.0.w, se.1.w, se.1.b, se.3.w, se.3.b (parameters / their gradients)
@@ -961,7 +1034,18 @@ int launch_flca_backward(const float* feat, const float* guide, const float* xs,
         flca_abg_kernel<<<1, 256, 0, st>>>(abg, B * nblk, grd[0], grd[1], grd[2]);
         if (int rc = check_launch("flca_backward")) return rc;
     }
-    // tap sums = 3x3 weight gradients with the guidance planes as (1- or 2-channel) inputs
+    // tap sums = 3x3 weight gradients with the guidance planes as (1- or 2-channel) inputs: one pass over ds
+    if (w % 4 == 0) {
+        int slab_px, per_image;
+        gram2_slabs(B, P, cdiv(C, 16), &slab_px, &per_image);
+        const int nslab = B * per_image;
+        float* sums = gpart + (size_t)nslab * C * 36;
+        ProfScope prof(st, "flca_taps_kernel", 2.0 * 36 * (double)B * C * P, 12.0 * (double)B * C * P);
+        flca_taps_kernel<<<dim3((unsigned)nslab, (unsigned)cdiv(C, 16)), 256, 0, st>>>(ds, plane, guide, gpart, C, h, w, slab_px, per_image);
+        reduce_partials_kernel<<<red_grid((size_t)C * 36), 256, 0, st>>>(gpart, sums, nslab, (size_t)C * 36, 0);
+        flca_taps_scatter_kernel<<<cdiv(C * 36, 256), 256, 0, st>>>(sums, grd[3], grd[4], grd[5], C);
+        return check_launch("flca_taps");
+    }
     if (int rc = launch_gram2(ds, (int64_t)C * P, C, guide, (int64_t)4 * P, 1, grd[3], 1, gpart, B, h, w, 9, 0, 0, 0, 0, 1, st)) return rc;
     if (int rc = launch_gram2(ds + plane, (int64_t)C * P, C, guide + P, (int64_t)4 * P, 1, grd[4], 1, gpart, B, h, w, 9, 0, 0, 0, 0, 1, st)) return rc;
     return launch_gram2(ds + 2 * plane, (int64_t)C * P, C, guide + 2 * (size_t)P, (int64_t)4 * P, 2, grd[5], 2, gpart, B, h, w, 9, 0, 0, 0, 0, 1, st);
