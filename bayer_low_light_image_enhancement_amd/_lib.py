@@ -26,6 +26,8 @@ _vp, _i, _f, _sz = C.c_void_p, C.c_int, C.c_float, C.c_size_t
 # rf_allreduce_fn (include/rawformer_hip.h): void (*)(void* user, float* buf, size_t n, int op, void* stream); buf arrives as an integer address
 ALLREDUCE_FN = C.CFUNCTYPE(None, C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_void_p)
 _psz = C.POINTER(C.c_size_t)
+# rf_grad_ready_fn: void (*)(void* user, size_t offset, size_t count, void* stream)
+GRAD_READY_FN = C.CFUNCTYPE(None, C.c_void_p, C.c_size_t, C.c_size_t, C.c_void_p)
 
 # name -> (restype, argtypes); mirrors include/rawformer_hip.h one to one
 SIGNATURES = {
@@ -47,6 +49,9 @@ SIGNATURES = {
     "rf_flat_param_floats": (_i, [_vp, _psz]),
     "rf_flat_offset": (_i, [_vp, _i, _psz]),
     "rf_train_workspace_bytes": (_i, [_vp, _i, _i, _i, _psz]),
+    "rf_set_grad_ready": (_i, [_vp, GRAD_READY_FN, _vp]),
+    "rf_grad_range_count": (_i, [_vp, C.POINTER(_i)]),
+    "rf_grad_range": (_i, [_vp, _i, _psz, _psz]),
     "rf_train_step": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _i, _i, _i, _i, _f, _vp]),
     "rf_adam_step": (_i, [_vp, _vp, _vp, _vp, _sz, _f, _f, _f, _f, _f, _i, _i, _f, _vp]),
     "rf_pixel_unshuffle2": (_i, [_vp, _vp, _i, _i, _i, _i, _vp]),

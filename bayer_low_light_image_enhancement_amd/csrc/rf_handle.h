@@ -43,6 +43,9 @@ struct rf_handle {
     int shard_y_lo = 0, shard_y_hi = 0, shard_total_rows = 0;
     void (*shard_allreduce)(void* user, float* buf, size_t n, int op, void* stream) = nullptr;
     void* shard_user = nullptr;
+    // training: notification that a range of the flat gradient buffer is final (rf_set_grad_ready)
+    void (*grad_ready)(void* user, size_t offset, size_t count, void* stream) = nullptr;
+    void* grad_ready_user = nullptr;
 };
 
 

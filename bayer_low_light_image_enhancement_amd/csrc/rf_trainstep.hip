@@ -19,6 +19,8 @@
 //     i.e. d[q;k] = M2 [q;k] with a per-image 2C x 2C matrix and dv = blockdiag(A^T) do: two 1x1 GEMMs with per-image weights.
 // Variants 'plain' (conv branch) and 'flca' (rf_train.hip: launch_flca_backward).
 #include <cstring>
+#include <string>
+#include <vector>
 #include "rf_handle.h"
 
 using namespace rf;
@@ -481,7 +483,57 @@ int stage_backward(const Ctx& c, int i, int lvl, float* dout, float* din, int H,
 
 }  // namespace
 
+// Modules in the order their gradients become final = reverse registry order (the registry is in forward order).
+std::vector<std::string> grad_order(const rf_handle* h) {
+    (void)h;
+    return {"conv_out.", "conv_tran7.", "up3.", "conv_tran6.", "up2.", "conv_tran5.", "up1.", "conv_tran4.", "conv_tran3.", "conv_tran2.", "conv_tran1.", "embedding."};
+}
+// first flat float of the module with this prefix ("up<i>." is followed by "channel_reduce<i>." in the registry, "conv_tran<i>." by
+// "down<i>.": a range runs from its module's first float to the previous watermark, so those ride along)
+size_t module_start(const rf_handle* h, const std::string& prefix) {
+    size_t best = h->flat_floats;
+    for (size_t i = 0; i < h->params.size(); ++i)
+        if (h->params[i].name.compare(0, prefix.size(), prefix) == 0 && h->flat_offset[i] < best) best = h->flat_offset[i];
+    return best;
+}
+struct GradNotifier {
+    const rf_handle* h; hipStream_t st; size_t watermark;
+    void done(const std::string& prefix) {
+        const size_t lo = module_start(h, prefix);
+        if (lo >= watermark) return;
+        if (h->grad_ready) h->grad_ready(h->grad_ready_user, lo, watermark - lo, (void*)st);
+        watermark = lo;
+    }
+};
+
 extern "C" {
+
+int rf_set_grad_ready(rf_handle* h, rf_grad_ready_fn ready, void* user) {
+    RF_CHECK_ARG(h, "rf_set_grad_ready: null handle");
+    h->grad_ready = ready; h->grad_ready_user = ready ? user : nullptr;
+    return RF_OK;
+}
+
+int rf_grad_range_count(const rf_handle* h, int* count) {
+    RF_CHECK_ARG(h && count, "rf_grad_range_count: null argument");
+    size_t wm = h->flat_floats; int n = 0;
+    for (const std::string& m : grad_order(h)) { const size_t lo = module_start(h, m); if (lo < wm) { ++n; wm = lo; } }
+    *count = n;
+    return RF_OK;
+}
+
+int rf_grad_range(const rf_handle* h, int index, size_t* offset, size_t* count) {
+    RF_CHECK_ARG(h && offset && count && index >= 0, "rf_grad_range: bad arguments");
+    size_t wm = h->flat_floats; int n = 0;
+    for (const std::string& m : grad_order(h)) {
+        const size_t lo = module_start(h, m);
+        if (lo >= wm) continue;
+        if (n == index) { *offset = lo; *count = wm - lo; return RF_OK; }
+        ++n; wm = lo;
+    }
+    set_error("rf_grad_range: index %d out of range (%d ranges)", index, n);
+    return RF_E_INVALID;
+}
 
 int rf_flat_param_floats(const rf_handle* h, size_t* floats) {
     RF_CHECK_ARG(h && floats, "rf_flat_param_floats: null argument");
@@ -564,6 +616,8 @@ int rf_train_step(rf_handle* h, const float* in, const float* gt, float* grads, 
     RF_TRY(launch_pixel_unshuffle2(p.pred, tB, B, oc, H, W, st));
     RF_TRY(launch_ewise(tA, tB, tA, (size_t)B * 4 * oc * H * W, 2, 0.2f, st));
     RF_TRY(b_conv3x3_dw(c, tA, 4 * oc, p.st[7].out, d, c.G("conv_out.weight"), c.G("conv_out.bias"), H, W));
+    GradNotifier note{h, st, h->flat_floats};
+    note.done("conv_out.");
     float* tE_src = p.tC;
     RF_TRY(b_conv3x3_dx(c, tA, 4 * oc, P(h, "conv_out.weight"), d, tE_src, H, W));    // d(stage 7 out)
     for (int l = 0; l < 3; ++l) RF_TRY(check_hip(hipMemsetAsync(p.dskip[l], 0, ((size_t)B * (d << l) * (H >> l) * (W >> l)) * 4, st), "memset dskip"));
@@ -575,6 +629,7 @@ int rf_train_step(rf_handle* h, const float* in, const float* gt, float* grads, 
         const int lvl = 3 - i, C = d << lvl, hh = H >> lvl, ww = W >> lvl, Pn = hh * ww;
         const std::string u = "up" + std::to_string(i), r = "channel_reduce" + std::to_string(i);
         RF_TRY(stage_backward(c, 4 + i, lvl, ga, gb, H, W));                                   // gb = d(catr_i)
+        note.done("conv_tran" + std::to_string(4 + i) + ".");
         // channel_reduce_i over cat[up, skip]
         RF_TRY(b_conv1x1_dw(c, gb, C, p.up[i - 1], C, c.G(r + ".weight"), 2 * C, 0, c.G(r + ".bias"), hh, ww));
         RF_TRY(b_conv1x1_dw(c, gb, C, p.st[lvl + 1].out, C, c.G(r + ".weight"), 2 * C, C, nullptr, hh, ww));
@@ -591,6 +646,7 @@ int rf_train_step(rf_handle* h, const float* in, const float* gt, float* grads, 
         a.x1 = p.tB; a.C1 = 4 * C; a.x1_bstride = (int64_t)4 * C * (Pn / 4); a.wp = p.wt1;
         a.out = ga; a.out_bstride = (int64_t)2 * C * (Pn / 4); a.Cout = 2 * C; a.B = B; a.P = Pn / 4; a.w = ww / 2;
         RF_TRY(launch_conv1x1(a, st));                                                         // ga = d(previous stage out) [B, 2C, Pn/4]
+        note.done(u + ".");                                                                    // up_i and channel_reduce_i
     }
     // bottleneck and encoder, bottom-up: ga = d(stage i out) on entry (for i <= 3 after the Downsample adjoint and the skip gradient)
     for (int i = 4; i >= 1; --i) {
@@ -603,10 +659,13 @@ int rf_train_step(rf_handle* h, const float* in, const float* gt, float* grads, 
             RF_TRY(launch_ewise(ga, p.dskip[lvl], ga, (size_t)B * C * Pn, 0, 0.f, st));
         }
         RF_TRY(stage_backward(c, i, lvl, ga, gb, H, W));                                       // gb = d(stage i input)
+        note.done("conv_tran" + std::to_string(i) + ".");                                      // and down_i, whose gradient came first
     }
     float* dcur = gb;
     // embedding
     RF_TRY(b_conv3x3_dw(c, dcur, d, p.x4, 4, c.G("embedding.weight"), c.G("embedding.bias"), H, W));
+    note.done("embedding.");
+    if (note.watermark != 0 && h->grad_ready) h->grad_ready(h->grad_ready_user, 0, note.watermark, (void*)st);      // anything in front (never, by construction)
     return RF_OK;
 }
 

@@ -38,11 +38,48 @@ def allreduce_flat(flat: torch.Tensor, group=None, bucket_floats: int = 1 << 20)
         w.wait()
 
 
+class OverlappedReducer:
+    """All-reduce of the flat gradient buffer OVERLAPPED with the backward pass (the reference reduces inside backward through
+    ``nn.DataParallel``, train.py:108-111).  ``rf_train_step`` announces ranges of the flat buffer whose gradients are final, from
+    the end of the buffer towards its start (``rf_set_grad_ready``); ``ready`` coalesces them into buckets of at least
+    ``bucket_floats`` and starts each bucket's asynchronous all-reduce at once -- with the ``nccl`` backend (RCCL) the collective
+    is ordered behind the kernels already enqueued on the current stream and runs beside the rest of the backward pass; ``finish``
+    waits for all of them.  Works on any tensor / backend (the CPU tests drive it with ``gloo``)."""
+
+    def __init__(self, flat: torch.Tensor, group=None, bucket_floats: int = 1 << 20):
+        self.flat, self.group, self.bucket_floats = flat, group, int(bucket_floats)
+        self.works, self.buckets = [], []
+        self.hi = self.lo = flat.numel()
+
+    def begin(self) -> None:
+        self.works, self.buckets = [], []
+        self.hi = self.lo = self.flat.numel()
+
+    def ready(self, offset: int, count: int) -> None:
+        import torch.distributed as dist
+        if offset + count != self.lo:
+            raise RuntimeError(f"gradient ranges must arrive contiguously from the end: got [{offset}, {offset + count}), expected to end at {self.lo}")
+        self.lo = offset
+        if self.hi - self.lo >= self.bucket_floats or self.lo == 0:
+            if self.hi > self.lo:
+                self.buckets.append((self.lo, self.hi))
+                self.works.append(dist.all_reduce(self.flat[self.lo:self.hi], op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+            self.hi = self.lo
+
+    def finish(self) -> None:
+        if self.lo != 0:
+            raise RuntimeError(f"gradient ranges stopped at float {self.lo}: the step did not announce the whole buffer")
+        for w in self.works:
+            w.wait()
+        self.works = []
+
+
 class Trainer:
     """Owns the flat parameter / gradient / moment buffers of a ``RawFormer`` and runs training steps on them."""
 
     def __init__(self, model: RawFormer, lr: float = 1e-4, betas=(0.9, 0.999), eps: float = 1e-8, weight_decay: float = 0.0,
-                 decoupled: bool = False, loss: str = "l1", charbonnier_eps: float = 1e-3, group=None):
+                 decoupled: bool = False, loss: str = "l1", charbonnier_eps: float = 1e-3, group=None, overlap_allreduce: bool = True,
+                 bucket_floats: int = 1 << 20):
         if model.variant not in ("plain", "flca"):
             raise RuntimeError("Trainer: the adjoint schedule exists for variants 'plain' and 'flca'")
         dev = next(model.parameters()).device
@@ -75,6 +112,11 @@ class Trainer:
         self.step_no = 0
         self.workspace: Optional[torch.Tensor] = None
         self.loss_dev = torch.zeros(1, dtype=torch.float32, device=dev)
+        # gradient all-reduce started range by range from inside rf_train_step (several ranks only)
+        self.overlap = bool(overlap_allreduce)
+        self.reducer = OverlappedReducer(self.grads, group, bucket_floats)
+        self._reduced = False
+        self._ready_cb = _lib.GRAD_READY_FN(lambda user, off, cnt, stream: self.reducer.ready(int(off), int(cnt)))   # kept alive with the Trainer
         model.invalidate_packed()
 
     def grad_of(self, key: str) -> torch.Tensor:
@@ -100,16 +142,26 @@ class Trainer:
                 self.workspace = torch.empty(sz.value, dtype=torch.uint8, device=x.device)
             pred = torch.empty_like(gt) if want_pred else None
             stream = C.c_void_p(torch.cuda.current_stream(x.device).cuda_stream)
+            import torch.distributed as dist
+            overlapped = self.overlap and dist.is_initialized() and dist.get_world_size(self.group) > 1
+            _lib.check(lib.rf_set_grad_ready(self.state.handle, self._ready_cb if overlapped else _lib.GRAD_READY_FN(), None), "rf_set_grad_ready")
+            if overlapped:
+                self.reducer.begin()
             _lib.check(lib.rf_train_step(self.state.handle, C.c_void_p(x.data_ptr()), C.c_void_p(gt.data_ptr()), C.c_void_p(self.grads.data_ptr()),
                                          C.c_void_p(self.loss_dev.data_ptr()), C.c_void_p(pred.data_ptr() if want_pred else None),
                                          C.c_void_p(self.workspace.data_ptr()), self.workspace.numel(), b, H, W, self.loss_mode, self.loss_eps,
                                          stream), "rf_train_step")
+            self._reduced = overlapped          # the buckets are on the wire (or done); optimizer_step waits for them
         return (self.loss_dev, pred) if want_pred else self.loss_dev
 
     def optimizer_step(self):
         import torch.distributed as dist
         world = dist.get_world_size(self.group) if dist.is_initialized() else 1
-        allreduce_flat(self.grads, self.group)
+        if self._reduced:
+            self.reducer.finish()
+            self._reduced = False
+        else:
+            allreduce_flat(self.grads, self.group)
         self.step_no += 1
         lib = _lib.load()
         dev = self.flat.device

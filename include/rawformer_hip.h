@@ -115,6 +115,16 @@ int rf_forward_stage(rf_handle* h, int stage, const float* in, const float* pack
 int rf_flat_param_floats(const rf_handle* h, size_t* floats);
 int rf_flat_offset(const rf_handle* h, int index, size_t* offset);
 int rf_train_workspace_bytes(const rf_handle* h, int B, int H, int W, size_t* bytes);
+/* Overlap of the gradient all-reduce with the backward pass (the reference reduces inside backward through nn.DataParallel,
+ * train.py:108-111).  The registry -- and so the flat buffer -- is in FORWARD order, the backward finishes modules in reverse
+ * order: rf_train_step calls `ready(user, offset, count, stream)` each time the gradients of flat floats [offset, offset + count)
+ * are final (their last kernel has been enqueued on `stream`), from the end of the buffer towards its start, every float
+ * exactly once.  The host starts its collective for that range behind those kernels.  NULL switches the notifications off.
+ * rf_grad_range_count / rf_grad_range: the ranges a step will announce, in announcement order (static per model). */
+typedef void (*rf_grad_ready_fn)(void* user, size_t offset, size_t count, void* stream);
+int rf_set_grad_ready(rf_handle* h, rf_grad_ready_fn ready, void* user);
+int rf_grad_range_count(const rf_handle* h, int* count);
+int rf_grad_range(const rf_handle* h, int index, size_t* offset, size_t* count);
 int rf_train_step(rf_handle* h, const float* in, const float* gt, float* grads, float* loss_out, float* pred_out, void* workspace,
                   size_t workspace_bytes, int B, int H, int W, int loss_mode, float loss_eps, void* stream);
 /* torch.optim.Adam / AdamW (decoupled != 0) on flat buffers; grads are multiplied by grad_scale first (1 / world size). */

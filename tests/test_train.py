@@ -202,3 +202,100 @@ def test_bucketed_gradient_allreduce_two_gloo_ranks(tmp_path):
     mp.spawn(_ddp_worker, args=(2, _free_port(), out), nprocs=2, join=True)
     g = torch.load(out, weights_only=True)
     assert torch.equal(g, torch.arange(10_000, dtype=torch.float32) * 3)
+
+
+def _overlap_worker(rank, world, port, out):
+    """Two gloo ranks: a stand-in backward fills the flat gradient buffer range by range in the order rf_train_step announces
+    (rf_grad_range, from a REAL handle: host logic, no GPU) and hands every range to OverlappedReducer; the result must equal the
+    serial bucketed all-reduce of the same gradients, bit for bit."""
+    import ctypes as C
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from bayer_low_light_image_enhancement_amd import RawFormer, _lib
+    from bayer_low_light_image_enhancement_amd.train import OverlappedReducer, allreduce_flat
+    lib = _lib.load()
+    m = RawFormer(dim=32)
+    cfg = m._config()
+    h = C.c_void_p()
+    _lib.check(lib.rf_create(C.byref(cfg), C.byref(h)), "rf_create")
+    n, cnt = C.c_size_t(), C.c_int()
+    _lib.check(lib.rf_flat_param_floats(h, C.byref(n)), "floats")
+    _lib.check(lib.rf_grad_range_count(h, C.byref(cnt)), "count")
+    ranges = []
+    off, num = C.c_size_t(), C.c_size_t()
+    for i in range(cnt.value):
+        _lib.check(lib.rf_grad_range(h, i, C.byref(off), C.byref(num)), "range")
+        ranges.append((off.value, num.value))
+    lib.rf_destroy(h)
+    # the ranges tile the buffer from its end to its start
+    assert ranges[0][0] + ranges[0][1] == n.value and ranges[-1][0] == 0
+    assert all(ranges[i][0] == ranges[i + 1][0] + ranges[i + 1][1] for i in range(len(ranges) - 1))
+    g = torch.Generator().manual_seed(100 + rank)
+    grads = torch.randn(n.value, generator=g)
+    serial = grads.clone()
+    allreduce_flat(serial)
+    flat = torch.zeros(n.value)
+    red = OverlappedReducer(flat, bucket_floats=1 << 18)
+    red.begin()
+    for lo, c in ranges:                       # "backward": this range's gradients become final, then it is announced
+        flat[lo:lo + c] = grads[lo:lo + c]
+        red.ready(lo, c)
+    red.finish()
+    assert torch.equal(flat, serial)
+    assert len(red.buckets) >= 4 and red.buckets[0][1] == n.value and red.buckets[-1][0] == 0      # several buckets, whole buffer
+    if rank == 0:
+        torch.save({"ranges": ranges, "buckets": red.buckets, "n": n.value}, out)
+    dist.destroy_process_group()
+
+
+def test_overlapped_gradient_allreduce_equals_the_serial_one_two_gloo_ranks(tmp_path):
+    out = str(tmp_path / "o.pt")
+    mp.spawn(_overlap_worker, args=(2, _free_port(), out), nprocs=2, join=True)
+    rec = torch.load(out, weights_only=True)
+    assert rec["n"] > 2_000_000 and len(rec["ranges"]) == 12          # RawFormer-S (FLCA): 2.48 M gradients in 12 module ranges
+
+
+@pytest.mark.gpu
+def test_train_step_announces_every_gradient_once_and_in_order(device):
+    """rf_train_step calls the gradient-ready callback for [offset, offset + count) from the end of the flat buffer to its start,
+    every float exactly once, matching rf_grad_range; at each call the announced gradients are already final on the stream
+    (compared after the step with a step run without callback)."""
+    import ctypes as C
+    from bayer_low_light_image_enhancement_amd import RawFormer, _lib
+    from bayer_low_light_image_enhancement_amd.train import Trainer
+    dim, seed, b, hm, wm = 16, 93, 1, 32, 128
+    sd = cases.model_state(dim, seed, "flca")
+    m = RawFormer(dim=dim)
+    m.load_state_dict({**m.state_dict(), **sd}, strict=True)
+    m = m.to(device).train()
+    x = torch.from_numpy(synth.bayer_mosaic(seed, b, hm, wm)).to(device)
+    gt = torch.from_numpy(synth.smooth_rgb(seed, b, hm, wm)).to(device)
+    tr = Trainer(m)
+    tr.forward_backward(x, gt)
+    ref = tr.grads.clone()
+    calls, snaps = [], []
+
+    def cb(user, off, cnt, stream):
+        calls.append((int(off), int(cnt)))
+        snaps.append(tr.grads[int(off): int(off) + int(cnt)].clone())        # enqueued behind the gradient kernels on the same stream
+    keep = _lib.GRAD_READY_FN(cb)
+    lib = _lib.load()
+    _lib.check(lib.rf_set_grad_ready(tr.state.handle, keep, None), "rf_set_grad_ready")
+    tr.overlap = False                                        # keep our callback: forward_backward would otherwise reset it
+    lib_set = lib.rf_set_grad_ready
+    try:
+        lib.rf_set_grad_ready = lambda *a: 0                 # forward_backward must not clear the test's callback
+        tr.forward_backward(x, gt)
+    finally:
+        lib.rf_set_grad_ready = lib_set
+        _lib.check(lib.rf_set_grad_ready(tr.state.handle, _lib.GRAD_READY_FN(), None), "rf_set_grad_ready")
+    torch.cuda.synchronize()
+    assert calls and calls[0][0] + calls[0][1] == tr.n and calls[-1][0] == 0
+    assert all(calls[i][0] == calls[i + 1][0] + calls[i + 1][1] for i in range(len(calls) - 1))
+    n, off, num = C.c_int(), C.c_size_t(), C.c_size_t()
+    _lib.check(lib.rf_grad_range_count(tr.state.handle, C.byref(n)), "count")
+    assert n.value == len(calls)
+    for i, (o, c) in enumerate(calls):
+        _lib.check(lib.rf_grad_range(tr.state.handle, i, C.byref(off), C.byref(num)), "range")
+        assert (off.value, num.value) == (o, c)
+        assert torch.equal(snaps[i], ref[o:o + c]), (i, o, c)          # final at announcement time
