@@ -586,8 +586,10 @@ def feb(x: torch.Tensor, params, prefix: str = "") -> torch.Tensor:
     return out
 
 
-def ffab(x: torch.Tensor, params, prefix: str = "") -> torch.Tensor:
-    """``FFAB(nc)(x)`` (RawFomer_WFB_FFAB/blocks.py:59-92): seven ProcessBlocks (FEB + 1x1 + residual), dense concatenations."""
+def ffab(x: torch.Tensor, params, prefix: str = "", out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """``FFAB(nc)(x)`` (RawFomer_WFB_FFAB/blocks.py:59-92): seven ProcessBlocks (FEB + 1x1 + residual), dense concatenations.
+    ``out``: an existing contiguous tensor (or leading slice of one) of x's shape to write into -- lets a caller place the result
+    where the next operator reads it instead of concatenating afterwards."""
     x = _chk(x, "x")
     b, c, h, w = x.shape
     ts = [_chk(params[prefix + k], k) for k in _FFAB_KEYS]
@@ -595,7 +597,10 @@ def ffab(x: torch.Tensor, params, prefix: str = "") -> torch.Tensor:
     sz = C.c_size_t()
     _lib.check(lib.rf_ffab_scratch_bytes(b, c, h, w, C.byref(sz)), "rf_ffab_scratch_bytes")
     scratch = _scratch(sz.value, x)
-    out = torch.empty_like(x)
+    if out is None:
+        out = torch.empty_like(x)
+    elif tuple(out.shape) != tuple(x.shape) or not out.is_contiguous() or out.dtype != torch.float32 or out.device != x.device:
+        raise RuntimeError(f"ffab: `out` must be a contiguous float32 tensor of shape {tuple(x.shape)} on {x.device}")
     with torch.cuda.device(x.device):
         _lib.check(lib.rf_ffab(_ptr(x), _ptr(out), _ptr_array(ts), _ptr(scratch), b, c, h, w, _stream(x)), "rf_ffab")
     return out
@@ -610,10 +615,11 @@ def wmb_ll_branch(x: torch.Tensor, params, prefix: str = "", high=None) -> torch
     n = x.shape[0]
     t = layernorm2d(x, 2.0 * params[prefix + "norm1.body.weight"], 2.0 * params[prefix + "norm1.body.bias"] - 1.0)
     d = dwt_init(t)
-    fea, _ = illumination_estimator(d[:n].contiguous(), params, prefix + "illu.")
-    ll = ffab(fea, params, prefix + "ffab.")
-    hi = d[n:] if high is None else high(d[n:])
-    y = iwt_init(torch.cat((ll, hi), dim=0))
+    fea, _ = illumination_estimator(d[:n], params, prefix + "illu.")      # d[:n] = the LL band: a contiguous leading slice, no copy
+    if high is not None:
+        d[n:].copy_(high(d[n:]))                                         # the caller's module (Mamba in the reference) on the high bands
+    ffab(fea, params, prefix + "ffab.", out=d[:n])                        # LL band replaced in place: IWT reads [LL ; high] as it lies
+    y = iwt_init(d)
     out = torch.empty_like(t)
     with torch.cuda.device(x.device):
         _lib.check(_lib.load().rf_affine_clamp_add(_ptr(y), _ptr(t), _ptr(out), t.numel(), 0.5, 0.5, 0.0, 1.0, _stream(x)), "rf_affine_clamp_add")

@@ -45,7 +45,7 @@ def test_gpus_2_launches_two_ranks_batch_sharded():
 
 
 def test_cfg4_two_ranks_tile_sharded_with_the_all_gather_in_the_step():
-    r = _run("--gpus", "2", "--dry-run", "--workload", "cfg4", "--steps", "2", "--warmup", "1")
+    r = _run("--gpus", "2", "--dry-run", "--workload", "cfg4t", "--steps", "2", "--warmup", "1")
     assert r.returncode == 0, r.stderr[-2000:]
     line = _json_line(r.stdout)
     assert line["n_gpus"] == 2 and line["scaling"] == "strong"
@@ -54,8 +54,9 @@ def test_cfg4_two_ranks_tile_sharded_with_the_all_gather_in_the_step():
     _both_ranks_profiled(r, line)
 
 
-def test_cfg4x_two_ranks_exact_row_shards_with_their_collectives_in_the_step():
-    r = _run("--gpus", "2", "--dry-run", "--workload", "cfg4x", "--steps", "2", "--warmup", "1")
+@pytest.mark.parametrize("name", ["cfg4", "cfg4x"])          # BASELINE configs[3] runs in the exact mode by default
+def test_cfg4_two_ranks_exact_row_shards_with_their_collectives_in_the_step(name):
+    r = _run("--gpus", "2", "--dry-run", "--workload", name, "--steps", "2", "--warmup", "1")
     assert r.returncode == 0, r.stderr[-2000:]
     line = _json_line(r.stdout)
     assert line["n_gpus"] == 2 and line["scaling"] == "strong"
