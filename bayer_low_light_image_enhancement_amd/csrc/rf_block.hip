@@ -31,6 +31,13 @@ size_t transformer_scratch_floats(int B, int C, int heads, int hc, int h, int w,
     return off;
 }
 
+bool transformer_ffn_is_fused(const TbParams& p, int C, int hc, int hh, int ww) {
+#ifdef RF_DIAG
+    if (getenv("RF_NO_FUSE") || getenv("RF_NO_FUSE_FFN")) return false;
+#endif
+    return p.pw1_wp3 && fused_ffn_supported(C, hc, hh, ww);
+}
+
 int run_transformer(const TbParams& p, const float* in, float* out, float* ws, const TbBufOffsets& o,
                     int B, int C, int heads, int hc, int hh, int ww, hipStream_t st) {
     const int Pn = hh * ww;
@@ -42,9 +49,9 @@ int run_transformer(const TbParams& p, const float* in, float* out, float* ws, c
     float* wfold3 = ws + o.wfold3;
 #ifdef RF_DIAG   // diagnostic build only (build.py --diag): force the op-by-op path; the shipped library has no switch
     const bool no_fuse = getenv("RF_NO_FUSE") != nullptr;
-    const bool no_fuse_attn = no_fuse || getenv("RF_NO_FUSE_ATTN") != nullptr, no_fuse_ffn = no_fuse || getenv("RF_NO_FUSE_FFN") != nullptr;
+    const bool no_fuse_attn = no_fuse || getenv("RF_NO_FUSE_ATTN") != nullptr;
 #else
-    constexpr bool no_fuse = false, no_fuse_attn = false, no_fuse_ffn = false;
+    constexpr bool no_fuse = false, no_fuse_attn = false;
 #endif
 
     // x + attn(LN1(x)) ---------------------------------------------------------------------
@@ -106,7 +113,7 @@ int run_transformer(const TbParams& p, const float* in, float* out, float* ws, c
     RF_TRY(launch_conv1x1(av, st));
 
     // x + ffn(LN2(x)) ----------------------------------------------------------------------
-    if (!no_fuse_ffn && p.pw1_wp3 && fused_ffn_supported(C, hc, hh, ww)) {
+    if (transformer_ffn_is_fused(p, C, hc, hh, ww)) {
         // LN2 -> 1x1 -> depthwise 3x3 -> GELU -> 1x1 + residual in one kernel: the hidden tensor stays on chip
         RF_TRY(launch_ffn_fused(x1, out, p.ln2_w, p.ln2_b, p.pw1_wp3, p.pw1_b, p.dw_w, p.dw_b, p.pw2_wp, p.pw2_b, B, C, hh, ww, st));
     } else {
@@ -122,6 +129,7 @@ int run_transformer(const TbParams& p, const float* in, float* out, float* ws, c
         d2.w = p.dw_w; d2.bias = p.dw_b;
         d2.B = B; d2.C = hc; d2.h = hh; d2.w_ = ww; d2.gelu = 1;
         RF_TRY(launch_dwconv3x3(d2, st));
+        if (p.defer_pw2) return RF_OK;
 
         Conv1x1Args f2{};
         f2.x1 = bufB; f2.C1 = hc; f2.x1_bstride = (int64_t)hc * Pn;

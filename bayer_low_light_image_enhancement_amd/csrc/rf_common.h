@@ -155,6 +155,9 @@ struct Conv1x1Args {
     int C1, C2;            // channels taken from each source (K = C1 + C2)
     int64_t x1_bstride;    // floats between images in source 1
     int64_t x2_bstride;
+    const float* x3;       // third source (bf16x3 streaming kernel only: the composed Conv_Transformer tail, rf_model.hip) or nullptr
+    int C3;                // K = C1 + C2 + C3
+    int64_t x3_bstride;
     const float* wp;       // packed weights
     int64_t wp_bstride;    // floats between per-image weight sets (0 = shared)
     const void* wp3;       // the same weights in b3 form (packed1x1_b3_floats) or nullptr: selects the bf16x3 kernels
@@ -258,7 +261,12 @@ struct TbParams {
     int ylo = 0, yhi = 0;
     void (*allreduce)(void* user, float* buf, size_t n, int op, void* stream) = nullptr;
     void* allreduce_user = nullptr;
+    // composed stage tail: on the op-by-op FFN path stop after depthwise 3x3 + GELU -- x + attn(..) stays in the x1 buffer, the
+    // hidden tensor in bufB, `out` is not written; the caller's channel_reduce GEMM applies pointwise2 (transformer_ffn_is_fused
+    // tells it which path runs)
+    bool defer_pw2 = false;
 };
+bool transformer_ffn_is_fused(const TbParams& p, int C, int hc, int hh, int ww);
 struct TbBufOffsets { size_t bufA, bufB, x1, partial, wfold, wfold3; };   // float offsets into one scratch area
 size_t transformer_scratch_floats(int B, int C, int heads, int hc, int h, int w, TbBufOffsets* o);
 int run_transformer(const TbParams& p, const float* in, float* out, float* ws, const TbBufOffsets& o,
@@ -333,6 +341,13 @@ int launch_scale_channels(float* x, const float* ch, int B, int C, int P, hipStr
 // SE + fold into channel_reduce: wp_out[b] = pack([Wa * diag(ch_b) | Wb])
 int launch_flca_se_fold(const float* partial, int nblk, int P, const float* se1_w, const float* se1_b,
                         const float* se3_w, const float* se3_b, int hidden, const float* w_cr,
-                        float* wp_out, void* wp3_out /* b3 form too, or nullptr */, float* ch_out, int B, int C, hipStream_t st);
+                        float* wp_out, void* wp3_out /* b3 form too, or nullptr */, float* ch_out, int B, int C, hipStream_t st,
+                        const float* composed = nullptr /* pack_tail: emit [Wa diag(ch_b) | Wb | Wb W2] in b3 form only */, int hc = 0);
+// Composed stage tail (rf_model.hip run_stage): channel_reduce(cat(xs, x1 + W2 g + b2)) as ONE GEMM over [xs ; x1 ; g].
+// pack_tail writes Wb W2 ([C][hc]) and the composed bias ([C]) once per parameter load; launch_tail_fold the b3 weights.
+size_t tail_composed_floats(int C, int hc);
+int pack_tail(const float* w_cr, const float* b_cr, const float* w2, const float* b2, float* composed, int C, int hc, hipStream_t st);
+int launch_tail_fold(const float* w_cr, const float* ch /* [B][C] gate or nullptr */, const float* composed, void* wp3_out, int B, int C, int hc,
+                     hipStream_t st);
 
 }  // namespace rf

@@ -380,21 +380,64 @@ __global__ void __launch_bounds__(256) flca_se_kernel(const float* __restrict__ 
 }
 
 // wp_out[b] = pack([W_a diag(ch_b) | W_b]) in MFMA operand order
-// (and, when wp3_out is given, the same matrix in b3 form for the bf16x3 GEMM: rf_common.h)
-__global__ void __launch_bounds__(256) flca_fold_kernel(const float* __restrict__ w_cr, const float* __restrict__ ch,
-                                                        float* __restrict__ wp_out, unsigned short* __restrict__ wp3_out, int C) {
+// (and, when wp3_out is given, the same matrix in b3 form for the bf16x3 GEMM: rf_common.h).
+// With `wc` (tail_compose_kernel below: W_b W_2, [C][hc]) the matrix is [W_a diag(ch_b) | W_b | W_b W_2], K = 2C + hc, written in
+// b3 form only: the weights of the composed stage tail (rf_model.hip, run_stage).  ch == nullptr: no gate (plain variant).
+__global__ void __launch_bounds__(256) flca_fold_kernel(const float* __restrict__ w_cr, const float* __restrict__ ch, const float* __restrict__ wc,
+                                                        float* __restrict__ wp_out, unsigned short* __restrict__ wp3_out, int C, int hc) {
     const size_t b = blockIdx.y;
-    const int NT = (C + 15) >> 4, NS = (2 * C) >> 2, NB = (2 * C + 31) >> 5;
-    float* dst = wp_out + b * (size_t)NT * NS * 64;
+    const int K = 2 * C + (wc ? hc : 0);
+    const int NT = (C + 15) >> 4, NS = K >> 2, NB = (K + 31) >> 5;
+    float* dst = wp_out ? wp_out + b * (size_t)NT * NS * 64 : nullptr;
     unsigned short* dst3 = wp3_out ? wp3_out + b * (size_t)NT * NB * 1536 : nullptr;
     for (int idx = blockIdx.x * 256 + threadIdx.x; idx < NT * NB * 512; idx += gridDim.x * 256) {
         const int l = idx & 63, t = (idx >> 6) % NT, s = (idx >> 6) / NT;      // s runs over the 8 NB k-sets of the padded matrix
         const int co = 16 * t + (l & 15), k = 4 * s + (l >> 4);
         float v = 0.f;
-        if (co < C && k < 2 * C) v = w_cr[(size_t)co * 2 * C + k] * (k < C ? ch[b * C + k] : 1.0f);
-        if (s < NS) dst[((size_t)s * NT + t) * 64 + l] = v;
+        if (co < C && k < 2 * C) v = w_cr[(size_t)co * 2 * C + k] * ((k < C && ch) ? ch[b * C + k] : 1.0f);
+        else if (co < C && k < K) v = wc[(size_t)co * hc + (k - 2 * C)];
+        if (dst && s < NS) dst[((size_t)s * NT + t) * 64 + l] = v;
         if (dst3) b3_store(dst3, NT, co, k, v);
     }
+}
+
+// Composed stage tail, once per parameter load:  channel_reduce([xs ; x1 + W_2 g + b_2]) = W_a xs + W_b x1 + (W_b W_2) g + (W_b b_2 + b_cr)
+// out[co * hc + k] = sum_m W_cr[co][C + m] W_2[m][k]   (k < hc),   out[C * hc + co] = b_cr[co] + sum_m W_cr[co][C + m] b_2[m]
+__global__ void __launch_bounds__(256) tail_compose_kernel(const float* __restrict__ w_cr, const float* __restrict__ b_cr, const float* __restrict__ w2,
+                                                           const float* __restrict__ b2, float* __restrict__ out, int C, int hc) {
+    const int n = C * hc + C;
+    for (int idx = blockIdx.x * 256 + threadIdx.x; idx < n; idx += gridDim.x * 256) {
+        float v;
+        if (idx < C * hc) {
+            const int co = idx / hc, k = idx - co * hc;
+            v = 0.f;
+            for (int m = 0; m < C; ++m) v = fmaf(w_cr[(size_t)co * 2 * C + C + m], w2[(size_t)m * hc + k], v);
+        } else {
+            const int co = idx - C * hc;
+            v = b_cr ? b_cr[co] : 0.f;
+            if (b2) for (int m = 0; m < C; ++m) v = fmaf(w_cr[(size_t)co * 2 * C + C + m], b2[m], v);
+        }
+        out[idx] = v;
+    }
+}
+
+size_t tail_composed_floats(int C, int hc) { return (size_t)C * hc + C; }
+
+int pack_tail(const float* w_cr, const float* b_cr, const float* w2, const float* b2, float* composed, int C, int hc, hipStream_t st) {
+    tail_compose_kernel<<<cdiv(C * hc + C, 256), 256, 0, st>>>(w_cr, b_cr, w2, b2, composed, C, hc);
+    return check_launch("pack_tail");
+}
+
+static int fold_grid(int C, int K) {
+    const int gx = cdiv(cdiv(C, 16) * cdiv(K, 32) * 512, 256 * 4);
+    return gx < 1 ? 1 : gx;
+}
+
+// [W_a diag(ch_b) | W_b | W_b W_2] in b3 form for B images (ch == nullptr: B = 1 static set without a gate)
+int launch_tail_fold(const float* w_cr, const float* ch, const float* composed, void* wp3_out, int B, int C, int hc, hipStream_t st) {
+    RF_CHECK_ARG(w_cr && composed && wp3_out && C % 32 == 0 && hc % 32 == 0, "tail_fold: bad arguments (C = %d, hidden = %d)", C, hc);
+    flca_fold_kernel<<<dim3((unsigned)fold_grid(C, 2 * C + hc), (unsigned)B), 256, 0, st>>>(w_cr, ch, composed, nullptr, (unsigned short*)wp3_out, C, hc);
+    return check_launch("tail_fold");
 }
 
 int launch_flca_se(const float* partial, int nblk, int P, const float* se1_w, const float* se1_b,
@@ -418,13 +461,12 @@ int launch_scale_channels(float* x, const float* ch, int B, int C, int P, hipStr
 
 int launch_flca_se_fold(const float* partial, int nblk, int P, const float* se1_w, const float* se1_b,
                         const float* se3_w, const float* se3_b, int hidden, const float* w_cr,
-                        float* wp_out, void* wp3_out, float* ch_out, int B, int C, hipStream_t st) {
+                        float* wp_out, void* wp3_out, float* ch_out, int B, int C, hipStream_t st, const float* composed, int hc) {
     ProfScope prof(st, "flca_se_kernel+flca_fold_kernel", 0.0, 0.0);
     const int rc = launch_flca_se(partial, nblk, P, se1_w, se1_b, se3_w, se3_b, hidden, ch_out, B, C, st);
     if (rc) return rc;
-    int gx = cdiv(cdiv(C, 16) * cdiv(2 * C, 32) * 512, 256 * 4);
-    if (gx < 1) gx = 1;
-    flca_fold_kernel<<<dim3((unsigned)gx, (unsigned)B), 256, 0, st>>>(w_cr, ch_out, wp_out, (unsigned short*)wp3_out, C);
+    if (composed) return launch_tail_fold(w_cr, ch_out, composed, wp3_out, B, C, hc, st);
+    flca_fold_kernel<<<dim3((unsigned)fold_grid(C, 2 * C), (unsigned)B), 256, 0, st>>>(w_cr, ch_out, nullptr, wp_out, (unsigned short*)wp3_out, C, 0);
     return check_launch("flca_se_fold");
 }
 

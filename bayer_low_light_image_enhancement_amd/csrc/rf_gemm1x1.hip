@@ -449,6 +449,22 @@ __global__ void __launch_bounds__(256, 2) conv1x1_stream_kernel(Conv1x1Args a, i
 // 24 * NCO MFMAs of 17 cycles (f32 form: 32 * NCO MFMAs of 33 cycles).  The next block's x is loaded into the registers
 // the split has just vacated, its weights go registers -> LDS behind the MFMAs; one barrier per block.
 // ---------------------------------------------------------------------------------------------
+// channels 32c + 8kq + i (i = 0..7) of K block c, 4 pixels each: the block lies in ONE of up to three sources (launch_conv1x1
+// checks that they are cut at multiples of 32 channels); selects, not branches (see kset_base)
+__device__ __forceinline__ void b3_load_x_block(float4 (&xr)[8], const float* xb1, const float* xb2, const float* xb3, int C1, int C2, int C3,
+                                                int c, int kq, unsigned P, unsigned pl) {
+    const int cb = 32 * c;
+    const bool first = cb < C1, third = cb >= C1 + C2;
+    const float* src = first ? xb1 : third ? xb3 : xb2;
+    const int cloc = first ? cb : third ? cb - C1 - C2 : cb - C1, cmax = (first ? C1 : third ? C3 : C2) - 1;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        int ch = cloc + 8 * kq + i;
+        ch = ch < cmax ? ch : cmax;
+        xr[i] = ldv(src, (unsigned)ch * P + pl);
+    }
+}
+
 template <int NCO, bool LN>
 __global__ void __launch_bounds__(256, 2) conv1x1_b3_kernel(Conv1x1Args a, int ngroups) {
     __shared__ __attribute__((aligned(16))) u32x4 lds_w[2][NCO * 3 * 64];
@@ -462,7 +478,7 @@ __global__ void __launch_bounds__(256, 2) conv1x1_b3_kernel(Conv1x1Args a, int n
     const int tile = blockIdx.x / ngroups;
     const int b = blockIdx.y;
     const int P = a.P;
-    const int K = a.C1 + a.C2;
+    const int K = a.C1 + a.C2 + a.C3;
     const int NB = (K + 31) >> 5;
     const int NT = (a.Cout + 15) >> 4;
     const int t0 = grp * NCO;
@@ -529,18 +545,12 @@ __global__ void __launch_bounds__(256, 2) conv1x1_b3_kernel(Conv1x1Args a, int n
     u32x4 wr[WPT];
     // channel 32c + 8kq + i of block c: sources are cut at multiples of 32 channels (launch_conv1x1 checks), channels past K
     // re-read the last one (their weights are zero)
-    auto load_x_block = [&](int c) {
-        const int cb = 32 * c;
-        const bool first = cb < a.C1;
-        const float* src = (first ? a.x1 : a.x2) + (size_t)b * (size_t)(first ? a.x1_bstride : a.x2_bstride);
-        const int cloc = first ? cb : cb - a.C1, cmax = (first ? a.C1 : a.C2) - 1;
-#pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            int ch = cloc + 8 * kq + i;
-            ch = ch < cmax ? ch : cmax;
-            xr[i] = ldv(src, (unsigned)ch * (unsigned)P + pl);
-        }
-    };
+    // (the sources are passed BY VALUE to a function: a conditional between two variables captured by a lambda is a conditional
+    // between two addresses of its closure, and hipcc then keeps the closure -- and the xr registers it refers to -- in scratch)
+    const float* const xb1 = a.x1 + (size_t)b * (size_t)a.x1_bstride;
+    const float* const xb2 = a.x2 + (size_t)b * (size_t)a.x2_bstride;      // only dereferenced when C2 / C3 > 0
+    const float* const xb3 = a.x3 + (size_t)b * (size_t)a.x3_bstride;
+    auto load_x_block = [&](int c) { b3_load_x_block(xr, xb1, xb2, xb3, a.C1, a.C2, a.C3, c, kq, (unsigned)P, pl); };
     auto load_w_block = [&](int c) {
 #pragma unroll
         for (int i = 0; i < WPT; ++i) {
@@ -841,9 +851,9 @@ static void launch_res(const Conv1x1Args& a, int ntw, int ngroups, dim3 grid, si
 // f32 kernels, which read x once whatever Cout is and are HBM-bound there (measured per shape with tools/kbench.py:
 // b3 wins 1.05-1.4 x from K = 128 up, loses 0.75-0.95 x at K = 64)
 static bool b3_supported(const Conv1x1Args& a) {
-    const int K = a.C1 + a.C2;
-    return K >= 128 && a.C1 % 8 == 0 && a.C2 % 8 == 0 && (a.C2 == 0 || a.C1 % 32 == 0) && (!a.ln_w || K <= kStreamLnMaxK) &&
-           aligned16(a.wp3) && (a.wp3_bstride % 4 == 0);
+    const int K = a.C1 + a.C2 + a.C3;
+    return K >= 128 && a.C1 % 8 == 0 && a.C2 % 8 == 0 && a.C3 % 8 == 0 && (a.C2 + a.C3 == 0 || a.C1 % 32 == 0) &&
+           (a.C3 == 0 || a.C2 % 32 == 0) && (!a.ln_w || (K <= kStreamLnMaxK && a.C3 == 0)) && aligned16(a.wp3) && (a.wp3_bstride % 4 == 0);
 }
 
 int launch_conv1x1(const Conv1x1Args& a, hipStream_t st) {
@@ -851,12 +861,14 @@ int launch_conv1x1(const Conv1x1Args& a, hipStream_t st) {
                  a.B, a.P, a.C1, a.C2, a.Cout);
     RF_CHECK_ARG(a.C1 % 4 == 0 && a.C2 % 4 == 0, "conv1x1: input channel counts (%d, %d) must be multiples of 4", a.C1, a.C2);
     RF_CHECK_ARG(a.C2 == 0 || a.x2 != nullptr, "conv1x1: second source missing");
+    RF_CHECK_ARG(a.C3 >= 0 && a.C3 % 4 == 0 && (a.C3 == 0 || (a.x3 != nullptr && a.C2 > 0)), "conv1x1: bad third source (C3 = %d)", a.C3);
     RF_CHECK_ARG(a.mode == 0 || (a.Cout % 4 == 0 && a.w > 0 && a.P % a.w == 0 && !a.res), "conv1x1: bad ConvTranspose geometry");
     RF_CHECK_ARG(a.B <= 65535 && (double)a.P * 4.0 * 16.0 < 4.0e9, "conv1x1: batch %d / plane %d too large", a.B, a.P);
-    const int K = a.C1 + a.C2;
+    const int K = a.C1 + a.C2 + a.C3;
     const int NS = K / 4, NT = cdiv(a.Cout, 16);
     bool vec = (a.P % 4 == 0) && aligned16(a.x1) && aligned16(a.out) && (a.x1_bstride % 4 == 0) && (a.out_bstride % 4 == 0);
     if (a.x2) vec = vec && aligned16(a.x2) && (a.x2_bstride % 4 == 0);
+    if (a.C3) vec = vec && aligned16(a.x3) && (a.x3_bstride % 4 == 0);
     if (a.res) vec = vec && aligned16(a.res) && (a.res_bstride % 4 == 0);
     if (a.mode == 1) vec = vec && (a.w % 2 == 0);
     const double px = (double)a.B * a.P;
@@ -867,6 +879,8 @@ int launch_conv1x1(const Conv1x1Args& a, hipStream_t st) {
     if (getenv("RF_NO_B3")) b3_ok = false;
 #endif
     const bool use_b3 = b3_ok && b3_supported(a);
+    // three sources exist for the bf16x3 streaming kernel only (its caller checks the shape; there is no slower form to fall to)
+    RF_CHECK_ARG(a.C3 == 0 || (use_b3 && vec && !a.ln_w && !(a.res && a.Cout % 16 != 0)), "conv1x1: three sources need the bf16x3 kernel (K = %d, P = %d)", K, a.P);
     if (!vec || (a.res && a.Cout % 16 != 0) || (a.ln_w && K > kStreamLnMaxK)) {
         ProfScope prof(st, "conv1x1_scalar_kernel", work_flops, work_bytes);
         int gx = cdiv(a.P, 256);

@@ -35,6 +35,9 @@ struct rf_handle {
     std::unordered_map<std::string, int> pack3_index;  // weight name -> packs[] entry of its b3 form
     size_t packed_floats = 0;
     size_t upcat_offset[3] = {0, 0, 0};   // composed decoder-step weights (rf_upcat.hip), floats into the packed buffer
+    // composed stage tails (rf_flca.hip pack_tail): per Conv_Transformer stage 1..7, floats into the packed buffer of [Wb W2 | b']
+    // (0 = stage not composed) and, plain variant only, of the static b3 weights [Wa | Wb | Wb W2]
+    size_t tail_offset[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tail3_offset[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     const float* packed = nullptr;   // caller memory, valid after rf_pack_params
     std::vector<size_t> flat_offset;  // float offset of every parameter in the flat parameter / gradient buffers (training)
     size_t flat_floats = 0;

@@ -42,6 +42,11 @@ void add_pack(rf_handle* h, const std::string& name, PackKind kind) {
     h->packs.push_back(it);
 }
 
+// Stage tail  channel_reduce(cat(branch, x1 + pointwise2(g)))  as one bf16x3 GEMM over [branch ; x1 ; g] (K = 2C + hidden):
+// K blocks of 32 channels must not straddle the sources.  Level 0 of RawFormer-S / -B runs the fused FFN kernel instead
+// (run_stage decides per call: the fused kernel takes only some image sizes).
+bool tail_composable(int C, int hc) { return C % 32 == 0 && hc % 32 == 0 && hc > 0; }
+
 void add_stage(rf_handle* h, int i, int C, int heads) {
     const rf_config& cfg = h->cfg;
     const std::string pre = "conv_tran" + std::to_string(i) + ".";
@@ -118,6 +123,14 @@ void add_stage(rf_handle* h, int i, int C, int heads) {
         add_pack(h, pre + "channel_reduce.weight", PK_1x1);
         add_pack(h, pre + "channel_reduce.weight", PK_1x1_B3);
     }
+    if (tail_composable(C, hc)) {      // pointwise2 composed into channel_reduce (run_stage)
+        h->tail_offset[i] = h->packed_floats;
+        h->packed_floats += align_up(tail_composed_floats(C, hc), 64);
+        if (cfg.variant == RF_VARIANT_PLAIN) {
+            h->tail3_offset[i] = h->packed_floats;
+            h->packed_floats += align_up(packed1x1_b3_floats(2 * C + hc, C), 64);
+        }
+    }
     add_pack(h, pre + "Conv_out.weight", PK_3x3);
 }
 
@@ -180,7 +193,9 @@ int make_plan(const rf_handle* h, int B, int H, int W, Plan& p) {
         const size_t a = (size_t)B * packed1x1_floats(C, C), cr = (size_t)B * packed1x1_floats(2 * C, C);
         if (a > wa) wa = a;
         if (cr > wc) wc = cr;
-        const size_t a3 = (size_t)B * packed1x1_b3_floats(C, C), cr3 = (size_t)B * packed1x1_b3_floats(2 * C, C);
+        const int hcl = C * c.ffn_expansion;
+        const size_t a3 = (size_t)B * packed1x1_b3_floats(C, C),
+                     cr3 = (size_t)B * packed1x1_b3_floats(tail_composable(C, hcl) ? 2 * C + hcl : 2 * C, C);
         if (a3 > wa3) wa3 = a3;
         if (cr3 > wc3) wc3 = cr3;
         const size_t f = (size_t)B * (tc ? tc_nblk(H >> l, W >> l) : flca_nblk(H >> l, W >> l)) * C;
@@ -232,7 +247,16 @@ int run_stage(const rf_handle* h, int i, int lvl, const float* in, float* out, f
     const int P_pool = sharded ? (h->shard_total_rows >> lvl) * ww : Pn;
     if (sharded) { tp.ylo = ylo; tp.yhi = yhi; tp.allreduce = h->shard_allreduce; tp.allreduce_user = h->shard_user; }
     TbBufOffsets to{p.bufA, p.bufB, p.x1, p.gram_partial, p.wfold_attn, p.wfold_attn3};
+    // Composed tail: where the FFN runs op by op, its last GEMM (x1 + W2 g + b2 -> trans, K = hidden) and channel_reduce
+    // ([Wa' | Wb] [xs ; trans], K = 2C) become ONE GEMM over [xs ; x1 ; g] with [Wa' | Wb | Wb W2] (same MFMA count; `trans` --
+    // C floats per pixel written and read back -- never exists).  The bias and Wb W2 are composed at parameter load.
+    bool compose = h->tail_offset[i] != 0 && Pn % 4 == 0 && !transformer_ffn_is_fused(tp, C, hc, hh, ww);
+#ifdef RF_DIAG   // diagnostic build only: the two-GEMM form
+    if (getenv("RF_NO_COMPOSE") || getenv("RF_NO_B3")) compose = false;
+#endif
+    tp.defer_pw2 = compose;
     RF_TRY(run_transformer(tp, in, trans, ws, to, B, C, heads, hc, hh, ww, st));
+    const float* composed = compose ? h->packed + h->tail_offset[i] : nullptr;
 
     // branch, cat, channel_reduce -------------------------------------------------------------
     Conv1x1Args r{};
@@ -259,9 +283,9 @@ int run_stage(const rf_handle* h, int i, int lvl, const float* in, float* out, f
         const int hid = C / 8 > 8 ? C / 8 : 8;
         RF_TRY(launch_flca_se_fold(ws + p.flca_partial, tc_nblk(hh, ww), Pn, P(h, f + "se.1.weight"), P(h, f + "se.1.bias"),
                                    P(h, f + "se.3.weight"), P(h, f + "se.3.bias"), hid, P(h, pre + "channel_reduce.weight"),
-                                   ws + p.wfold_cr, ws + p.wfold_cr3, ws + p.ch, B, C, st));
+                                   ws + p.wfold_cr, ws + p.wfold_cr3, ws + p.ch, B, C, st, composed, hc));
         r.wp = ws + p.wfold_cr; r.wp_bstride = (int64_t)packed1x1_floats(2 * C, C);
-        r.wp3 = ws + p.wfold_cr3; r.wp3_bstride = (int64_t)packed1x1_b3_floats(2 * C, C);
+        r.wp3 = ws + p.wfold_cr3; r.wp3_bstride = (int64_t)packed1x1_b3_floats(compose ? 2 * C + hc : 2 * C, C);
     } else if (cfg.variant == RF_VARIANT_FLCA) {
         const std::string f = pre + "FLCA.";
         FlcaSpatialArgs s{};
@@ -275,9 +299,9 @@ int run_stage(const rf_handle* h, int i, int lvl, const float* in, float* out, f
         const int hid = C / 8 > 8 ? C / 8 : 8;
         RF_TRY(launch_flca_se_fold(s.partial, s.nblk, P_pool, P(h, f + "se.1.weight"), P(h, f + "se.1.bias"),
                                    P(h, f + "se.3.weight"), P(h, f + "se.3.bias"), hid, P(h, pre + "channel_reduce.weight"),
-                                   ws + p.wfold_cr, ws + p.wfold_cr3, ws + p.ch, B, C, st));
+                                   ws + p.wfold_cr, ws + p.wfold_cr3, ws + p.ch, B, C, st, composed, hc));
         r.wp = ws + p.wfold_cr; r.wp_bstride = (int64_t)packed1x1_floats(2 * C, C);
-        r.wp3 = ws + p.wfold_cr3; r.wp3_bstride = (int64_t)packed1x1_b3_floats(2 * C, C);
+        r.wp3 = ws + p.wfold_cr3; r.wp3_bstride = (int64_t)packed1x1_b3_floats(compose ? 2 * C + hc : 2 * C, C);
     } else {
         Conv3x3Args cb{};
         cb.x = in; cb.x_bstride = (int64_t)C * Pn; cb.wp = PK(h, pre + "conv.weight"); cb.bias = P(h, pre + "conv.bias");
@@ -285,7 +309,13 @@ int run_stage(const rf_handle* h, int i, int lvl, const float* in, float* out, f
         cb.act = cfg.branch_lrelu ? 1 : 0;
         RF_TRY(launch_conv3x3(cb, st));
         r.wp = PK(h, pre + "channel_reduce.weight");
-        r.wp3 = PK3(h, pre + "channel_reduce.weight");
+        r.wp3 = compose ? h->packed + h->tail3_offset[i] : PK3(h, pre + "channel_reduce.weight");
+    }
+    if (compose) {
+        r.wp = nullptr;
+        r.x2 = ws + p.x1;
+        r.x3 = ws + p.bufB; r.C3 = hc; r.x3_bstride = (int64_t)hc * Pn;
+        r.bias = composed + (size_t)C * hc;
     }
     RF_TRY(launch_conv1x1(r, st));
 
@@ -450,6 +480,16 @@ int rf_pack_params(rf_handle* h, void* packed_dev, size_t bytes, void* stream) {
         const int C = h->cfg.dim << (3 - i);
         const std::string u = "up" + std::to_string(i), r = "channel_reduce" + std::to_string(i);
         RF_TRY(pack_upcat(P(h, u + ".weight"), P(h, u + ".bias"), P(h, r + ".weight"), P(h, r + ".bias"), base + h->upcat_offset[i - 1], C, st));
+    }
+    for (int i = 1; i <= 7; ++i) {
+        if (!h->tail_offset[i]) continue;
+        const int lvl = i <= 4 ? i - 1 : 7 - i, C = h->cfg.dim << lvl, hc = C * h->cfg.ffn_expansion;
+        const std::string pre = "conv_tran" + std::to_string(i) + ".";
+        float* composed = base + h->tail_offset[i];
+        RF_TRY(pack_tail(P(h, pre + "channel_reduce.weight"), P(h, pre + "channel_reduce.bias"), P(h, pre + "Transformer.ffn.pointwise2.weight"),
+                         P(h, pre + "Transformer.ffn.pointwise2.bias"), composed, C, hc, st));
+        if (h->tail3_offset[i])
+            RF_TRY(launch_tail_fold(P(h, pre + "channel_reduce.weight"), nullptr, composed, base + h->tail3_offset[i], 1, C, hc, st));
     }
     h->packed = base;
     return RF_OK;

@@ -149,7 +149,7 @@ def test_interface_errors(device):
         with pytest.raises(RuntimeError, match="no CPU path"):
             m(torch.zeros(1, 1, 32, 32))
     m.train()
-    with pytest.raises(RuntimeError, match="inference only"):
+    with pytest.raises(RuntimeError, match="inference path"):
         m(torch.zeros(1, 1, 32, 32, device=device))
     with torch.no_grad():                                   # train() + no_grad is fine (validation loops)
         assert m(torch.zeros(1, 1, 32, 32, device=device)).shape == (1, 3, 32, 32)
