@@ -47,6 +47,8 @@ ProfScope::ProfScope(hipStream_t st, const char* key, double flops, double bytes
     g_prof.push_back(r);
 }
 
+bool profiling_active() { return g_prof_on; }
+
 ProfScope::~ProfScope() {
     if (rec_ >= 0) (void)hipEventRecord(g_prof[rec_].e1, st_);
 }

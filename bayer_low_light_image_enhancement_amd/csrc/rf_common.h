@@ -31,6 +31,7 @@ struct ProfScope {
     hipStream_t st_;
     int rec_;
 };
+bool profiling_active();   // between rf_profile_begin and rf_profile_end: schedules stay on ONE stream so the brackets mean what they say
 
 // GELU(v) = v/2 (1 + erf(v/sqrt 2)) with erf by Abramowitz-Stegun 7.1.26 (|error| <= 1.5e-7), arranged for the fewest
 // VALU operations (this sits next to MFMAs, and f32 VALU time adds to f32 MFMA time): with h = v/2 and

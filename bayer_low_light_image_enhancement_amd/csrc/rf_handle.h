@@ -46,6 +46,11 @@ struct rf_handle {
     int shard_y_lo = 0, shard_y_hi = 0, shard_total_rows = 0;
     void (*shard_allreduce)(void* user, float* buf, size_t n, int op, void* stream) = nullptr;
     void* shard_user = nullptr;
+    // branch stream (rf_forward): the guidance pyramid and each stage's FLCA / 3x3 branch run beside the TransformerBlock;
+    // forked from and joined into the caller's stream with the two events, created on first use
+    hipStream_t side = nullptr;
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+    bool side_failed = false;
     // training: notification that a range of the flat gradient buffer is final (rf_set_grad_ready)
     void (*grad_ready)(void* user, size_t offset, size_t count, void* stream) = nullptr;
     void* grad_ready_user = nullptr;

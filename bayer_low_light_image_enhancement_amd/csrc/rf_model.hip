@@ -217,9 +217,44 @@ int make_plan(const rf_handle* h, int B, int H, int W, Plan& p) {
         if (rc_) return rc_;  \
     } while (0)
 
+// ---- branch stream -------------------------------------------------------------------------
+// A stage's branch (FLCA gates + squeeze-excite fold, or the plain variant's 3x3) depends on the stage input only, like the
+// TransformerBlock beside it; so does the guidance pyramid at the head of the forward.  On a single frame every kernel of both
+// chains is a few dozen microseconds of mostly latency, so the branch runs on a second stream: fork = an event on the caller's
+// stream that the branch stream waits for, join = the reverse before channel_reduce.  Off while profiling (the per-kernel
+// brackets assume one stream), for a spatial shard (its collectives stay on the caller's stream) and for TrueColor (its
+// branch shares bufA with the block).
+hipStream_t branch_stream(rf_handle* h, hipStream_t st) {
+    if (h->side_failed || profiling_active() || h->shard_allreduce || h->cfg.variant == RF_VARIANT_TRUECOLOR) return st;
+#ifdef RF_DIAG   // diagnostic build only: everything on the caller's stream
+    if (getenv("RF_NO_SIDE")) return st;
+#endif
+    if (!h->side) {
+        if (hipStreamCreateWithFlags(&h->side, hipStreamNonBlocking) != hipSuccess ||
+            hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming) != hipSuccess ||
+            hipEventCreateWithFlags(&h->ev_join, hipEventDisableTiming) != hipSuccess) {
+            (void)hipGetLastError();
+            h->side_failed = true;       // no second stream: the single-stream schedule is always valid
+            h->side = nullptr;
+            return st;
+        }
+    }
+    return h->side;
+}
+int fork_branch(rf_handle* h, hipStream_t st, hipStream_t side) {
+    if (side == st) return RF_OK;
+    RF_TRY(check_hip(hipEventRecord(h->ev_fork, st), "branch fork (record)"));
+    return check_hip(hipStreamWaitEvent(side, h->ev_fork, 0), "branch fork (wait)");
+}
+int join_branch(rf_handle* h, hipStream_t st, hipStream_t side) {
+    if (side == st) return RF_OK;
+    RF_TRY(check_hip(hipEventRecord(h->ev_join, side), "branch join (record)"));
+    return check_hip(hipStreamWaitEvent(st, h->ev_join, 0), "branch join (wait)");
+}
+
 // one Conv_Transformer stage
-int run_stage(const rf_handle* h, int i, int lvl, const float* in, float* out, float* ws, const Plan& p,
-              int B, int H, int W, hipStream_t st) {
+int run_stage(rf_handle* h, int i, int lvl, const float* in, float* out, float* ws, const Plan& p,
+              int B, int H, int W, hipStream_t st, hipStream_t side) {
     const rf_config& cfg = h->cfg;
     const int C = cfg.dim << lvl, hh = H >> lvl, ww = W >> lvl, Pn = hh * ww, heads = cfg.heads[lvl];
     const int hc = C * cfg.ffn_expansion;
@@ -255,8 +290,11 @@ int run_stage(const rf_handle* h, int i, int lvl, const float* in, float* out, f
     if (getenv("RF_NO_COMPOSE") || getenv("RF_NO_B3")) compose = false;
 #endif
     tp.defer_pw2 = compose;
-    RF_TRY(run_transformer(tp, in, trans, ws, to, B, C, heads, hc, hh, ww, st));
     const float* composed = compose ? h->packed + h->tail_offset[i] : nullptr;
+    // the branch is launched first (on the branch stream when there is one), the block beside it; TrueColor's branch borrows
+    // bufA and therefore follows the block on the same stream
+    if (cfg.variant == RF_VARIANT_TRUECOLOR) RF_TRY(run_transformer(tp, in, trans, ws, to, B, C, heads, hc, hh, ww, st));
+    else RF_TRY(fork_branch(h, st, side));
 
     // branch, cat, channel_reduce -------------------------------------------------------------
     Conv1x1Args r{};
@@ -294,12 +332,12 @@ int run_stage(const rf_handle* h, int i, int lvl, const float* in, float* out, f
         s.alpha = P(h, f + "alpha"); s.beta = P(h, f + "beta"); s.gamma = P(h, f + "gamma");
         s.partial = ws + p.flca_partial; s.B = B; s.C = C; s.h = hh; s.w = ww; s.nblk = flca_nblk(hh, ww);
         s.ylo = ylo; s.yhi = yhi;
-        RF_TRY(launch_flca_spatial(s, st));
-        if (sharded) h->shard_allreduce(h->shard_user, s.partial, (size_t)B * s.nblk * C, 0, (void*)st);
+        RF_TRY(launch_flca_spatial(s, side));
+        if (sharded) h->shard_allreduce(h->shard_user, s.partial, (size_t)B * s.nblk * C, 0, (void*)side);
         const int hid = C / 8 > 8 ? C / 8 : 8;
         RF_TRY(launch_flca_se_fold(s.partial, s.nblk, P_pool, P(h, f + "se.1.weight"), P(h, f + "se.1.bias"),
                                    P(h, f + "se.3.weight"), P(h, f + "se.3.bias"), hid, P(h, pre + "channel_reduce.weight"),
-                                   ws + p.wfold_cr, ws + p.wfold_cr3, ws + p.ch, B, C, st, composed, hc));
+                                   ws + p.wfold_cr, ws + p.wfold_cr3, ws + p.ch, B, C, side, composed, hc));
         r.wp = ws + p.wfold_cr; r.wp_bstride = (int64_t)packed1x1_floats(2 * C, C);
         r.wp3 = ws + p.wfold_cr3; r.wp3_bstride = (int64_t)packed1x1_b3_floats(compose ? 2 * C + hc : 2 * C, C);
     } else {
@@ -307,9 +345,13 @@ int run_stage(const rf_handle* h, int i, int lvl, const float* in, float* out, f
         cb.x = in; cb.x_bstride = (int64_t)C * Pn; cb.wp = PK(h, pre + "conv.weight"); cb.bias = P(h, pre + "conv.bias");
         cb.out = xs; cb.out_bstride = (int64_t)C * Pn; cb.B = B; cb.Cin = C; cb.Cout = C; cb.h = hh; cb.w = ww;
         cb.act = cfg.branch_lrelu ? 1 : 0;
-        RF_TRY(launch_conv3x3(cb, st));
+        RF_TRY(launch_conv3x3(cb, side));
         r.wp = PK(h, pre + "channel_reduce.weight");
         r.wp3 = compose ? h->packed + h->tail3_offset[i] : PK3(h, pre + "channel_reduce.weight");
+    }
+    if (cfg.variant != RF_VARIANT_TRUECOLOR) {
+        RF_TRY(run_transformer(tp, in, trans, ws, to, B, C, heads, hc, hh, ww, st));
+        RF_TRY(join_branch(h, st, side));
     }
     if (compose) {
         r.wp = nullptr;
@@ -411,7 +453,13 @@ int rf_create(const rf_config* cfg, rf_handle** out) {
     return RF_OK;
 }
 
-void rf_destroy(rf_handle* h) { delete h; }
+void rf_destroy(rf_handle* h) {
+    if (!h) return;
+    if (h->side) (void)hipStreamDestroy(h->side);
+    if (h->ev_fork) (void)hipEventDestroy(h->ev_fork);
+    if (h->ev_join) (void)hipEventDestroy(h->ev_join);
+    delete h;
+}
 
 int rf_param_count(const rf_handle* h) { return h ? (int)h->params.size() : RF_E_INVALID; }
 
@@ -544,7 +592,7 @@ int rf_forward_stage(rf_handle* h, int stage, const float* in, const float* pack
         RF_TRY(launch_guidance_base(packed, 0, h->cfg.clamp_io, ws + p.gscratch, B, H, W, st));
         RF_TRY(launch_guidance_level(ws + p.gscratch, ws + p.guide[lvl], B, H, W, H >> lvl, W >> lvl, st));
     }
-    return run_stage(h, stage, lvl, in, out, ws, p, B, H, W, st);
+    return run_stage(h, stage, lvl, in, out, ws, p, B, H, W, st, st);
 }
 
 int rf_forward(rf_handle* h, const float* in, float* out, void* workspace, size_t workspace_bytes,
@@ -573,10 +621,13 @@ int rf_forward(rf_handle* h, const float* in, float* out, void* workspace, size_
     const int mosaic = packed_input ? 0 : 1;
 
     const int levels = cfg.flca_levels > 0 ? cfg.flca_levels : 2;
+    const hipStream_t side = branch_stream(h, st);
     if (cfg.variant == RF_VARIANT_FLCA) {
-        RF_TRY(launch_guidance_base(in, mosaic, cfg.clamp_io, ws + p.gscratch, B, H, W, st, h->shard_allreduce, h->shard_user));
+        // the guidance pyramid feeds the FLCA branches only: it runs on their stream, beside the embedding
+        RF_TRY(fork_branch(h, st, side));
+        RF_TRY(launch_guidance_base(in, mosaic, cfg.clamp_io, ws + p.gscratch, B, H, W, side, h->shard_allreduce, h->shard_user));
         for (int l = 0; l < 4; ++l)
-            RF_TRY(launch_guidance_level(ws + p.gscratch, ws + p.guide[l], B, H, W, H >> l, W >> l, st));
+            RF_TRY(launch_guidance_level(ws + p.gscratch, ws + p.guide[l], B, H, W, H >> l, W >> l, side));
     } else if (cfg.variant == RF_VARIANT_TRUECOLOR) {
         const std::string bp = "bayer_processor.";
         RF_TRY(launch_tc_front(in, mosaic, P(h, bp + "wb_gains"), P(h, bp + "color_matrix"),
@@ -599,14 +650,14 @@ int rf_forward(rf_handle* h, const float* in, float* out, void* workspace, size_
     float* skip[3] = {ws + p.skip[0], ws + p.skip[1], ws + p.skip[2]};
     for (int i = 1; i <= 3; ++i) {
         const int lvl = i - 1, C = d << lvl, hh = H >> lvl, ww = W >> lvl;
-        RF_TRY(run_stage(h, i, lvl, ws + p.tA, skip[lvl], ws, p, B, H, W, st));
+        RF_TRY(run_stage(h, i, lvl, ws + p.tA, skip[lvl], ws, p, B, H, W, st, side));
         Conv3x3Args dn{};
         dn.x = skip[lvl]; dn.x_bstride = (int64_t)C * hh * ww; dn.wp = PK(h, "down" + std::to_string(i) + ".body.0.weight");
         dn.out = ws + p.tA; dn.out_bstride = (int64_t)2 * C * (hh / 2) * (ww / 2);
         dn.B = B; dn.Cin = C; dn.Cout = C / 2; dn.h = hh; dn.w = ww; dn.store = 1;
         RF_TRY(launch_conv3x3(dn, st));
     }
-    RF_TRY(run_stage(h, 4, 3, ws + p.tA, ws + p.tB, ws, p, B, H, W, st));
+    RF_TRY(run_stage(h, 4, 3, ws + p.tA, ws + p.tB, ws, p, B, H, W, st, side));
     // decoder
     for (int i = 1; i <= 3; ++i) {
         const int lvl = 3 - i, C = d << lvl, hh = H >> lvl, ww = W >> lvl, Pn = hh * ww;
@@ -618,7 +669,7 @@ int rf_forward(rf_handle* h, const float* in, float* out, void* workspace, size_
         if (fuse_up) {
             // ConvTranspose2d + cat + 1x1 as one kernel on composed weights: `up` never reaches HBM
             RF_TRY(launch_upcat(ws + p.tB, skip[lvl], ws + p.tA, h->packed + h->upcat_offset[i - 1], B, C, hh / 2, ww / 2, st));
-            RF_TRY(run_stage(h, 4 + i, lvl, ws + p.tA, ws + p.tB, ws, p, B, H, W, st));
+            RF_TRY(run_stage(h, 4 + i, lvl, ws + p.tA, ws + p.tB, ws, p, B, H, W, st, side));
             continue;
         }
         Conv1x1Args up{};
@@ -632,7 +683,7 @@ int rf_forward(rf_handle* h, const float* in, float* out, void* workspace, size_
         cr.wp = PK(h, r + ".weight"); cr.bias = P(h, r + ".bias");
         cr.out = ws + p.tA; cr.out_bstride = (int64_t)C * Pn; cr.Cout = C; cr.B = B; cr.P = Pn; cr.w = ww;
         RF_TRY(launch_conv1x1(cr, st));
-        RF_TRY(run_stage(h, 4 + i, lvl, ws + p.tA, ws + p.tB, ws, p, B, H, W, st));
+        RF_TRY(run_stage(h, 4 + i, lvl, ws + p.tA, ws + p.tB, ws, p, B, H, W, st, side));
     }
     // conv_out + LeakyReLU + PixelShuffle (+ clamp)
     Conv3x3Args o{};
