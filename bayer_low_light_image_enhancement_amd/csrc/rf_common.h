@@ -206,6 +206,7 @@ struct DwConvArgs {
     const float* bias;     // [C] or nullptr
     int B, C, h, w_;
     int gelu;
+    float* out2 = nullptr; // training forward: out keeps the pre-activation, out2 (layout of out) receives GELU(out) with the exact erf
 };
 int launch_dwconv3x3(const DwConvArgs& a, hipStream_t st);
 int launch_pixel_unshuffle2(const float* in, float* out, int B, int C, int h, int w, hipStream_t st);
@@ -295,11 +296,13 @@ int launch_tc_color_head(float* x, const float* const* prm, int B, size_t P, hip
 // ---- training kernels (rf_train.hip)
 size_t gram2_partial_floats(int B, int Ca, int Cb, int h, int w, int ntap);
 int launch_gram2(const float* a, int64_t a_bstride, int Ca, const float* b, int64_t b_bstride, int Cb, float* out, int ld, float* partial,
-                 int B, int h, int w, int ntap, int sy, int sx, int per_image, size_t out_istride, int accumulate, hipStream_t st);
+                 int B, int h, int w, int ntap, int sy, int sx, int per_image, size_t out_istride, int accumulate, hipStream_t st,
+                 float* db = nullptr /* [Ca] (+)= row sums of a over all images and pixels: the bias gradient of the same layer */);
 int launch_reduce_rows(const float* partial, float* out, int nrows, size_t n, int accumulate, hipStream_t st);
 int chan_sum_nblk(int P);
 int launch_chan_sum(const float* x, int64_t bstride, float* out, float* partial, int B, int C, int P, int accumulate, hipStream_t st);
 size_t ln_bwd_partial_floats(int B, int C, int P);
+bool ln_bwd_fused_shape(int C, int P);   // true: launch_ln_bwd takes a strided residual for this shape
 int launch_ln_bwd(const float* x, const float* dy, const float* gamma, float* dx, float* dgb, float* partial,
                   int B, int C, int P, float eps, int accumulate_dx, int accumulate_w, hipStream_t st,
                   const float* res = nullptr, int64_t res_bstride = 0);
@@ -339,6 +342,7 @@ int launch_flca_se(const float* partial, int nblk, int P, const float* se1_w, co
                    const float* se3_w, const float* se3_b, int hidden, float* ch_out, int B, int C, hipStream_t st);
 // x[b][c][:] *= ch[b][c]   (operator-level FLCA output; the forward folds the gate into the next 1x1 instead)
 int launch_scale_channels(float* x, const float* ch, int B, int C, int P, hipStream_t st);
+int launch_scale_channels_to(const float* in, float* out, const float* ch, int B, int C, int P, hipStream_t st);   // out = in * ch (in == out allowed)
 // SE + fold into channel_reduce: wp_out[b] = pack([Wa * diag(ch_b) | Wb])
 int launch_flca_se_fold(const float* partial, int nblk, int P, const float* se1_w, const float* se1_b,
                         const float* se3_w, const float* se3_b, int hidden, const float* w_cr,

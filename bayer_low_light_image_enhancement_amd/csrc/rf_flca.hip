@@ -447,17 +447,33 @@ int launch_flca_se(const float* partial, int nblk, int P, const float* se1_w, co
     return check_launch("flca_se");
 }
 
-__global__ void __launch_bounds__(256) scale_channels_kernel(float* __restrict__ x, const float* __restrict__ ch, int P, size_t total) {
-    for (size_t i = blockIdx.x * 256ull + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) x[i] *= ch[i / P];
+// out = in * ch[b][c]  (in == out: in place), 16 bytes per lane when the plane size allows
+__global__ void __launch_bounds__(256) scale_channels_kernel(const float* in, float* out, const float* __restrict__ ch, int P, size_t total) {
+    for (size_t i = blockIdx.x * 256ull + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) out[i] = in[i] * ch[i / P];
+}
+__global__ void __launch_bounds__(256) scale_channels4_kernel(const float4* in, float4* out, const float* __restrict__ ch, int P4, size_t total4) {
+    for (size_t i = blockIdx.x * 256ull + threadIdx.x; i < total4; i += (size_t)gridDim.x * 256) {
+        const float s = ch[i / P4];
+        float4 v = in[i];
+        v.x *= s; v.y *= s; v.z *= s; v.w *= s;
+        out[i] = v;
+    }
 }
 
-int launch_scale_channels(float* x, const float* ch, int B, int C, int P, hipStream_t st) {
+int launch_scale_channels_to(const float* in, float* out, const float* ch, int B, int C, int P, hipStream_t st) {
     const size_t total = (size_t)B * C * P;
-    int g = (int)((total + 255) / 256);
-    if (g > 4096) g = 4096;
-    scale_channels_kernel<<<g, 256, 0, st>>>(x, ch, P, total);
+    if (P % 4 == 0 && aligned16(in) && aligned16(out)) {
+        size_t g = (total / 4 + 255) / 256;
+        if (g > 16384) g = 16384;
+        scale_channels4_kernel<<<(unsigned)g, 256, 0, st>>>(reinterpret_cast<const float4*>(in), reinterpret_cast<float4*>(out), ch, P / 4, total / 4);
+    } else {
+        int g = (int)((total + 255) / 256);
+        if (g > 4096) g = 4096;
+        scale_channels_kernel<<<g, 256, 0, st>>>(in, out, ch, P, total);
+    }
     return check_launch("scale_channels");
 }
+int launch_scale_channels(float* x, const float* ch, int B, int C, int P, hipStream_t st) { return launch_scale_channels_to(x, x, ch, B, C, P, st); }
 
 int launch_flca_se_fold(const float* partial, int nblk, int P, const float* se1_w, const float* se1_b,
                         const float* se3_w, const float* se3_b, int hidden, const float* w_cr,

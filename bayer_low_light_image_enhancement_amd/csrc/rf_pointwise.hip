@@ -423,6 +423,7 @@ __global__ void __launch_bounds__(kBlock) dwconv3x3_kernel(DwConvArgs a) {
         const size_t b = pl / a.C;
         const float* x = a.x + b * a.x_bstride + (size_t)c * h * w;
         float* o = a.out + b * a.out_bstride + (size_t)c * h * w;
+        float* o2 = a.out2 ? a.out2 + b * a.out_bstride + (size_t)c * h * w : nullptr;
         float k[9];
 #pragma unroll
         for (int i = 0; i < 9; ++i) k[i] = a.w[c * 9 + i];
@@ -489,12 +490,24 @@ __global__ void __launch_bounds__(kBlock) dwconv3x3_kernel(DwConvArgs a) {
                     *reinterpret_cast<float2*>(o + (size_t)y * w + x0) = make_float2(acc[r][0], acc[r][1]);
                 else
                     o[(size_t)y * w + x0] = acc[r][0];
+                if (o2) {      // the training forward keeps both sides of the activation (rf_trainstep.hip)
+                    float gv[VEC];
+#pragma unroll
+                    for (int p = 0; p < VEC; ++p) gv[p] = 0.5f * acc[r][p] * (1.0f + erff(acc[r][p] * 0.70710678118654752440f));
+                    if constexpr (VEC == 4)
+                        *reinterpret_cast<float4*>(o2 + (size_t)y * w + x0) = make_float4(gv[0], gv[1], gv[2], gv[3]);
+                    else if constexpr (VEC == 2)
+                        *reinterpret_cast<float2*>(o2 + (size_t)y * w + x0) = make_float2(gv[0], gv[1]);
+                    else
+                        o2[(size_t)y * w + x0] = gv[0];
+                }
             }
         }
     }
 }
 
 int launch_dwconv3x3(const DwConvArgs& a, hipStream_t st) {
+    RF_CHECK_ARG(!a.out2 || (!a.gelu && aligned16(a.out2)), "dwconv3x3: out2 is the activated copy of a pre-activation out (gelu = 0), 16-byte aligned");
     const bool vec = (a.w_ & 3) == 0 && aligned16(a.x) && aligned16(a.out) && (a.x_bstride & 3) == 0 && (a.out_bstride & 3) == 0;
     const double el = (double)a.B * a.C * a.h * a.w_;
     const bool tall = vec && a.h % 8 == 0;   // 8 output rows per thread: 10 row loads per 8 rows instead of 6 per 4

@@ -32,14 +32,17 @@ struct Gram2Args {
     const float* b; int64_t b_bstride; int Cb;     // input [B][Cb][h][w]
     float* partial;
     int B, h, w, sy, sx, slab_px, slabs_per_image;
+    float* bias_partial;                           // [slab][Ca] row sums of A (the bias gradient of the same layer) or nullptr
 };
 
 // NA (single-tap form only): A tiles per workgroup.  With one A tile the B rows were re-read once per 16 output rows (Ca = 96:
 // 2.25 x the algorithmic bytes, 0.22 of HBM); NA = Ca / 16 (up to 6) reads both operands once.
-template <int NTAP, int NA>
+// TJ: B tiles per workgroup (single-tap form: 4, or 2 when Cb <= 32 -- with four, half the loads and MFMAs of every level-0
+// layer were spent on clamped duplicate rows).  The row sums of A -- the bias gradient of the layer whose weight gradient this
+// is -- are accumulated per lane on the way (4 NA additions beside 16 NA TJ MFMAs) instead of by a second pass over dOut.
+template <int NTAP, int NA, int TJ>
 __global__ void __launch_bounds__(256) gram2_kernel(Gram2Args g) {
-    constexpr int TJ = NTAP == 1 ? 4 : 1;
-    static_assert(NTAP == 1 || NA == 1, "several A tiles only in the single-tap form");
+    static_assert(NTAP == 1 || (NA == 1 && TJ == 1), "several A / B tiles only in the single-tap form");
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int r = lane & 15, kq = lane >> 4;
     const int slab = blockIdx.x, ti = blockIdx.y, tjg = blockIdx.z;
@@ -63,6 +66,9 @@ __global__ void __launch_bounds__(256) gram2_kernel(Gram2Args g) {
     for (int k = 0; k < NTAP * NA; ++k)
 #pragma unroll
         for (int t = 0; t < TJ; ++t) acc[k][t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    float bsum[NA];
+#pragma unroll
+    for (int u = 0; u < NA; ++u) bsum[u] = 0.f;
 
     // The 4 pixels of a lane sit in one row (w % 4 == 0).  A step's loads -- the A row, and per B tile three rows of (16 bytes +
     // the two outer taps) for the 3x3 window, or one shifted row -- are all UNCONDITIONAL on clamped addresses (values masked
@@ -100,6 +106,8 @@ __global__ void __launch_bounds__(256) gram2_kernel(Gram2Args g) {
         float aa[NA][4];
 #pragma unroll
         for (int u = 0; u < NA; ++u) { aa[u][0] = q.ok ? q.a[u].x : 0.f; aa[u][1] = q.ok ? q.a[u].y : 0.f; aa[u][2] = q.ok ? q.a[u].z : 0.f; aa[u][3] = q.ok ? q.a[u].w : 0.f; }
+#pragma unroll
+        for (int u = 0; u < NA; ++u) bsum[u] += (aa[u][0] + aa[u][1]) + (aa[u][2] + aa[u][3]);
 #pragma unroll
         for (int t = 0; t < TJ; ++t) {
             float v[NROW][6];
@@ -153,6 +161,21 @@ __global__ void __launch_bounds__(256) gram2_kernel(Gram2Args g) {
             if (gi < g.Ca && gj < g.Cb)
                 g.partial[(((size_t)slab * NTAP + tap) * g.Ca + gi) * g.Cb + gj] = ((red[0][i][j] + red[1][i][j]) + red[2][i][j]) + red[3][i][j];
         }
+    if (g.bias_partial && tjg == 0) {      // row sums: the four pixel groups of a row, then the four waves, in a fixed order
+        __syncthreads();
+#pragma unroll
+        for (int u = 0; u < NA; ++u) {
+            float v = bsum[u];
+            v += __shfl_xor(v, 16);
+            v += __shfl_xor(v, 32);
+            if (kq == 0) red[wave][u][r] = v;
+        }
+        __syncthreads();
+        if (threadIdx.x < NA * 16) {
+            const int u = threadIdx.x >> 4, i = threadIdx.x & 15, gi = 16 * (ti * NA + u) + i;
+            if (gi < g.Ca) g.bias_partial[(size_t)slab * g.Ca + gi] = ((red[0][u][i] + red[1][u][i]) + red[2][u][i]) + red[3][u][i];
+        }
+    }
 }
 
 // out[e] (+)= sum over slabs of partial[slab][e], in slab order
@@ -187,14 +210,23 @@ __global__ void __launch_bounds__(256) reduce_partials_kernel(const float* __res
 
 // gram2 partials [group][slab_in_group][tap][Ca][Cb] -> out[group][(i * ld + j) * ntap + tap]   (weight layout [Cout][Cin][taps];
 // group = image when the result is wanted per image, else one group over all slabs)
+// bias_partial / db (optional, one group only): db[i] (+)= sum over slabs of bias_partial[slab][i], handled by the blocks that
+// follow the weight elements
 __global__ void __launch_bounds__(256) reduce_gram2_kernel(const float* __restrict__ partial, float* __restrict__ out, int nslab_per_group, int ntap,
-                                                           int Ca, int Cb, int ld, size_t out_gstride, int accumulate) {
+                                                           int Ca, int Cb, int ld, size_t out_gstride, int accumulate,
+                                                           const float* __restrict__ bias_partial, float* __restrict__ db) {
     __shared__ float lds[kRedParts][kRedElems];
-    const size_t n = (size_t)ntap * Ca * Cb;
+    const size_t n = (size_t)ntap * Ca * Cb, nb = db ? (size_t)Ca : 0, n_pad = (n + kRedElems - 1) / kRedElems * kRedElems;
     const int grp = blockIdx.y;
     const float* pg = partial + (size_t)grp * nslab_per_group * n;
-    for (size_t e0 = (size_t)blockIdx.x * kRedElems; e0 < n; e0 += (size_t)gridDim.x * kRedElems) {
+    for (size_t e0 = (size_t)blockIdx.x * kRedElems; e0 < n_pad + nb; e0 += (size_t)gridDim.x * kRedElems) {
         const size_t e = e0 + threadIdx.x % kRedElems;
+        if (e0 >= n_pad) {                                   // block-uniform: a block of bias elements
+            const size_t i = e - n_pad;
+            const float s = slab_sum(bias_partial + (i < nb ? i : 0), (size_t)Ca, nslab_per_group, i < nb, lds);
+            if (threadIdx.x < kRedElems && i < nb) db[i] = accumulate ? db[i] + s : s;
+            continue;
+        }
         const float s = slab_sum(pg + (e < n ? e : 0), n, nslab_per_group, e < n, lds);
         if (threadIdx.x < kRedElems && e < n) {
             const int j = (int)(e % Cb), i = (int)((e / Cb) % Ca), tap = (int)(e / ((size_t)Ca * Cb));
@@ -604,35 +636,44 @@ static int gram2_na(int Ca, int ntap) {
     return nt % 2 == 0 ? 2 : 1;
 }
 
+static int gram2_tj(int Cb, int ntap) { return ntap != 1 ? 1 : Cb <= 32 ? 2 : 4; }
+
 size_t gram2_partial_floats(int B, int Ca, int Cb, int h, int w, int ntap) {
     int px, per;
-    gram2_slabs(B, h * w, cdiv(Ca, 16 * gram2_na(Ca, ntap)) * cdiv(Cb, ntap == 1 ? 64 : 16), &px, &per);
-    return (size_t)B * per * ntap * Ca * Cb;
+    gram2_slabs(B, h * w, cdiv(Ca, 16 * gram2_na(Ca, ntap)) * cdiv(Cb, 16 * gram2_tj(Cb, ntap)), &px, &per);
+    return (size_t)B * per * ((size_t)ntap * Ca * Cb + Ca);      // + the row sums of A (bias gradient)
 }
 
 // out[(i * ld + j) * ntap + tap] = weight layout [Ca][ld >= Cb][taps] (ntap = 9: the 3x3 window in (dy, dx) row-major order;
 // ntap = 1: the single shift (sy, sx)); per_image: out[b * out_istride + ...] without the sum over images; accumulate adds
 int launch_gram2(const float* a, int64_t a_bstride, int Ca, const float* b, int64_t b_bstride, int Cb, float* out, int ld, float* partial,
-                 int B, int h, int w, int ntap, int sy, int sx, int per_image, size_t out_istride, int accumulate, hipStream_t st) {
+                 int B, int h, int w, int ntap, int sy, int sx, int per_image, size_t out_istride, int accumulate, hipStream_t st, float* db) {
     RF_CHECK_ARG(w % 4 == 0 && aligned16(a) && aligned16(b) && a_bstride % 4 == 0 && b_bstride % 4 == 0,
                  "gram2: width %d must be a multiple of 4 and the operands 16-byte aligned", w);
     RF_CHECK_ARG(ntap == 1 || ntap == 9, "gram2: ntap must be 1 or 9");
     RF_CHECK_ARG(ntap == 9 || sx == 0, "gram2: the single-tap form shifts rows only (sx = %d)", sx);
-    Gram2Args g{a, a_bstride, Ca, b, b_bstride, Cb, partial, B, h, w, sy, sx, 0, 0};
-    const int na = gram2_na(Ca, ntap);
-    gram2_slabs(B, h * w, cdiv(Ca, 16 * na) * cdiv(Cb, ntap == 1 ? 64 : 16), &g.slab_px, &g.slabs_per_image);
+    RF_CHECK_ARG(!db || !per_image, "gram2: the bias gradient is a sum over all images");
+    Gram2Args g{a, a_bstride, Ca, b, b_bstride, Cb, partial, B, h, w, sy, sx, 0, 0, nullptr};
+    const int na = gram2_na(Ca, ntap), tj = gram2_tj(Cb, ntap);
+    gram2_slabs(B, h * w, cdiv(Ca, 16 * na) * cdiv(Cb, 16 * tj), &g.slab_px, &g.slabs_per_image);
     const int nslab = B * g.slabs_per_image;
-    ProfScope prof(st, ntap == 1 ? "gram2_kernel<1>" : "gram2_kernel<9>", 2.0 * ntap * Ca * Cb * (double)B * h * w, 4.0 * (double)B * h * w * (Ca + Cb));
-    const dim3 grid1((unsigned)nslab, (unsigned)cdiv(Ca, 16 * na), (unsigned)cdiv(Cb, 64));
-    if (ntap == 9) gram2_kernel<9, 1><<<dim3((unsigned)nslab, (unsigned)cdiv(Ca, 16), (unsigned)cdiv(Cb, 16)), 256, 0, st>>>(g);
-    else if (na == 6) gram2_kernel<1, 6><<<grid1, 256, 0, st>>>(g);
-    else if (na == 4) gram2_kernel<1, 4><<<grid1, 256, 0, st>>>(g);
-    else if (na == 3) gram2_kernel<1, 3><<<grid1, 256, 0, st>>>(g);
-    else if (na == 2) gram2_kernel<1, 2><<<grid1, 256, 0, st>>>(g);
-    else gram2_kernel<1, 1><<<grid1, 256, 0, st>>>(g);
     const size_t n = (size_t)ntap * Ca * Cb;
-    reduce_gram2_kernel<<<dim3((unsigned)red_grid(n), per_image ? (unsigned)B : 1u), 256, 0, st>>>(
-        partial, out, per_image ? g.slabs_per_image : nslab, ntap, Ca, Cb, ld, out_istride, accumulate);
+    if (db) g.bias_partial = partial + (size_t)nslab * n;
+    ProfScope prof(st, ntap == 1 ? "gram2_kernel<1>" : "gram2_kernel<9>", 2.0 * ntap * Ca * Cb * (double)B * h * w, 4.0 * (double)B * h * w * (Ca + Cb));
+    const dim3 grid1((unsigned)nslab, (unsigned)cdiv(Ca, 16 * na), (unsigned)cdiv(Cb, 16 * tj));
+#define RF_G2(NA_, TJ_) gram2_kernel<1, NA_, TJ_><<<grid1, 256, 0, st>>>(g)
+#define RF_G2_TJ(NA_) do { if (tj == 2) RF_G2(NA_, 2); else RF_G2(NA_, 4); } while (0)
+    if (ntap == 9) gram2_kernel<9, 1, 1><<<dim3((unsigned)nslab, (unsigned)cdiv(Ca, 16), (unsigned)cdiv(Cb, 16)), 256, 0, st>>>(g);
+    else if (na == 6) RF_G2_TJ(6);
+    else if (na == 4) RF_G2_TJ(4);
+    else if (na == 3) RF_G2_TJ(3);
+    else if (na == 2) RF_G2_TJ(2);
+    else RF_G2_TJ(1);
+#undef RF_G2_TJ
+#undef RF_G2
+    const size_t n_pad = (n + kRedElems - 1) / kRedElems * kRedElems;
+    reduce_gram2_kernel<<<dim3((unsigned)red_grid(n_pad + (db ? Ca : 0)), per_image ? (unsigned)B : 1u), 256, 0, st>>>(
+        partial, out, per_image ? g.slabs_per_image : nslab, ntap, Ca, Cb, ld, out_istride, accumulate, g.bias_partial, db);
     return check_launch("gram2");
 }
 
@@ -668,6 +709,13 @@ static int launch_ln_bwd_reg(const float* x, const float* dy, const float* gamma
     reduce_partials_kernel<<<red_grid(2 * C), 256, 0, st>>>(partial, dgb, B * nblk, (size_t)2 * C, accumulate_w);
     return check_launch("ln_bwd");
 }
+// channel counts of the register-resident kernel (which also takes a strided residual); anything else runs the generic path
+bool ln_bwd_fused_shape(int C, int P) {
+    switch (C) {
+        case 16: case 32: case 48: case 64: case 96: case 128: case 192: case 256: case 384: case 512: return (P & 3) == 0;
+        default: return false;
+    }
+}
 int launch_ln_bwd(const float* x, const float* dy, const float* gamma, float* dx, float* dgb, float* partial,
                   int B, int C, int P, float eps, int accumulate_dx, int accumulate_w, hipStream_t st, const float* res, int64_t res_bstride) {
     ProfScope prof(st, "ln_bwd", 14.0 * B * C * P, (res ? 16.0 : 12.0) * B * C * P);
@@ -693,8 +741,9 @@ int launch_ln_bwd(const float* x, const float* dy, const float* gamma, float* dx
     float* stats = partial;
     float* sums = partial + align_up((size_t)B * 2 * P, 64);
     if (res) {
-        RF_CHECK_ARG(!accumulate_dx && res_bstride == (int64_t)C * P, "ln_bwd: the generic path takes a contiguous residual");
-        if (int rc = launch_ewise(res, nullptr, dx, (size_t)B * C * P, 5, 0.f, st)) return rc;       // dx = res, then accumulate
+        RF_CHECK_ARG(res_bstride == (int64_t)C * P, "ln_bwd: the generic path takes a contiguous residual");
+        // dx = res (or dx += res), then the adjoint accumulates
+        if (int rc = launch_ewise(res, accumulate_dx ? dx : nullptr, dx, (size_t)B * C * P, accumulate_dx ? 0 : 5, 0.f, st)) return rc;
         accumulate_dx = 1;
     }
     ln_bwd_kernel<<<dim3((unsigned)cdiv(P, 256), (unsigned)B), 256, 0, st>>>(x, dy, gamma, dx, stats, C, P, eps, accumulate_dx);
@@ -790,63 +839,78 @@ __global__ void __launch_bounds__(256) flca_dch_kernel(const float* __restrict__
     if (threadIdx.x == 0) partial[((size_t)b * nblk + blk) * C + c] = (ws[0] + ws[1]) + (ws[2] + ws[3]);
 }
 
-// squeeze-excite backward, ONE workgroup looping over the images in order (weight gradients accumulate deterministically).
-// in: pooled sums partial (forward: flca partial / P = mean), dch partials;  out: dm[b][c] / P, gradients of se.1.{w,b}, se.3.{w,b}
+// squeeze-excite backward, one workgroup per image (a single workgroup walking the images in turn took 120 us per stage):
+// in: pooled sums partial (forward: flca partial / P = mean), dch partials;  out: dm[b][c] / P and the image's CONTRIBUTION to the
+// gradients of se.1.{w,b}, se.3.{w,b} in contrib[b][hid C | hid | C hid | C] (the order of the four tensors in the flat gradient
+// buffer), summed over the images in order by reduce_partials_kernel: deterministic.
 __global__ void __launch_bounds__(256) flca_se_bwd_kernel(const float* __restrict__ pool_partial, int pool_nblk, const float* __restrict__ dch_partial, int dch_nblk,
                                                           const float* __restrict__ w1, const float* __restrict__ b1, const float* __restrict__ w3, const float* __restrict__ b3,
-                                                          float* __restrict__ dmP, float* __restrict__ gw1, float* __restrict__ gb1, float* __restrict__ gw3, float* __restrict__ gb3,
-                                                          int B, int C, int hid, int P) {
+                                                          float* __restrict__ dmP, float* __restrict__ contrib, int C, int hid, int P) {
     __shared__ float mean[512], dch[512], ds3[512], hv[64], dh[64];
-    __shared__ float colsum[8][64];
-    for (int b = 0; b < B; ++b) {
-        // column sums of the two partial tables: 64 channels x 4 row parts per pass, parts combined in a fixed order
-        // (one thread per channel walking up to 1024 rows made this kernel 240 us)
-        for (int c0 = 0; c0 < C; c0 += 64) {
-            const int c = c0 + (threadIdx.x & 63), part = threadIdx.x >> 6;
-            float s = 0.f, d = 0.f;
-            if (c < C) {
-                for (int k = part; k < pool_nblk; k += 4) s += pool_partial[((size_t)b * pool_nblk + k) * C + c];
-                for (int k = part; k < dch_nblk; k += 4) d += dch_partial[((size_t)b * dch_nblk + k) * C + c];
+    __shared__ float part[2][256];
+    const size_t b = blockIdx.x;
+    // column sums of the two partial tables: cw channels x nsl row slices per pass, 8 loads in flight per thread, slices
+    // combined in a fixed order (the forward's flca_se_kernel sums its table the same way)
+    const int cw = C < 256 ? C : 256, nsl = 256 / cw;
+    for (int c0 = 0; c0 < C; c0 += cw) {
+        const int c = c0 + threadIdx.x % cw, sl = threadIdx.x / cw;
+        float s = 0.f, d = 0.f;
+        if (sl < nsl && c < C) {
+            const float* src = pool_partial + b * pool_nblk * C + c;
+            int k = sl;
+            for (; k + 7 * nsl < pool_nblk; k += 8 * nsl) {
+                float t[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) t[u] = src[(size_t)(k + u * nsl) * C];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) s += t[u];
             }
-            colsum[part][threadIdx.x & 63] = s;
-            colsum[4 + part][threadIdx.x & 63] = d;
-            __syncthreads();
-            if (part == 0 && c < C) {
-                const int l = threadIdx.x & 63;
-                mean[c] = (((colsum[0][l] + colsum[1][l]) + colsum[2][l]) + colsum[3][l]) / (float)P;
-                dch[c] = ((colsum[4][l] + colsum[5][l]) + colsum[6][l]) + colsum[7][l];
-            }
-            __syncthreads();
+            for (; k < pool_nblk; k += nsl) s += src[(size_t)k * C];
+            const float* dsrc = dch_partial + b * dch_nblk * C + c;
+            for (int q = sl; q < dch_nblk; q += nsl) d += dsrc[(size_t)q * C];
         }
-        for (int m = threadIdx.x; m < hid; m += 256) {
-            float s = b1[m];
-            for (int c = 0; c < C; ++c) s = fmaf(w1[m * C + c], mean[c], s);
-            hv[m] = fmaxf(s, 0.f);
+        part[0][threadIdx.x] = s;
+        part[1][threadIdx.x] = d;
+        __syncthreads();
+        if (threadIdx.x < cw && c0 + threadIdx.x < C) {
+            float t = 0.f, u = 0.f;
+            for (int q = 0; q < nsl; ++q) { t += part[0][q * cw + threadIdx.x]; u += part[1][q * cw + threadIdx.x]; }
+            mean[c0 + threadIdx.x] = t / (float)P;
+            dch[c0 + threadIdx.x] = u;
         }
         __syncthreads();
-        for (int c = threadIdx.x; c < C; c += 256) {
-            float s = b3[c];
-            for (int m = 0; m < hid; ++m) s = fmaf(w3[c * hid + m], hv[m], s);
-            const float chv = sigm(s);
-            ds3[c] = dch[c] * chv * (1.0f - chv);
-        }
-        __syncthreads();
-        for (int m = threadIdx.x; m < hid; m += 256) {
-            float s = 0.f;
-            for (int c = 0; c < C; ++c) s = fmaf(w3[c * hid + m], ds3[c], s);
-            dh[m] = hv[m] > 0.f ? s : 0.f;
-        }
-        __syncthreads();
-        for (int e = threadIdx.x; e < C * hid; e += 256) gw3[e] += ds3[e / hid] * hv[e % hid];       // [C][hid]
-        for (int c = threadIdx.x; c < C; c += 256) gb3[c] += ds3[c];
-        for (int e = threadIdx.x; e < hid * C; e += 256) gw1[e] += dh[e / C] * mean[e % C];          // [hid][C]
-        for (int m = threadIdx.x; m < hid; m += 256) gb1[m] += dh[m];
-        for (int c = threadIdx.x; c < C; c += 256) {
-            float s = 0.f;
-            for (int m = 0; m < hid; ++m) s = fmaf(w1[m * C + c], dh[m], s);
-            dmP[(size_t)b * C + c] = s / (float)P;
-        }
-        __syncthreads();
+    }
+    for (int m = threadIdx.x; m < hid; m += 256) {
+        float s = b1[m];
+        for (int c = 0; c < C; ++c) s = fmaf(w1[m * C + c], mean[c], s);
+        hv[m] = fmaxf(s, 0.f);
+    }
+    __syncthreads();
+    for (int c = threadIdx.x; c < C; c += 256) {
+        float s = b3[c];
+        for (int m = 0; m < hid; ++m) s = fmaf(w3[c * hid + m], hv[m], s);
+        const float chv = sigm(s);
+        ds3[c] = dch[c] * chv * (1.0f - chv);
+    }
+    __syncthreads();
+    for (int m = threadIdx.x; m < hid; m += 256) {
+        float s = 0.f;
+        for (int c = 0; c < C; ++c) s = fmaf(w3[c * hid + m], ds3[c], s);
+        dh[m] = hv[m] > 0.f ? s : 0.f;
+    }
+    __syncthreads();
+    float* gw1 = contrib + b * (size_t)(2 * C * hid + hid + C);
+    float* gb1 = gw1 + (size_t)hid * C;
+    float* gw3 = gb1 + hid;
+    float* gb3 = gw3 + (size_t)C * hid;
+    for (int e = threadIdx.x; e < hid * C; e += 256) gw1[e] = dh[e / C] * mean[e % C];          // [hid][C]
+    for (int m = threadIdx.x; m < hid; m += 256) gb1[m] = dh[m];
+    for (int e = threadIdx.x; e < C * hid; e += 256) gw3[e] = ds3[e / hid] * hv[e % hid];       // [C][hid]
+    for (int c = threadIdx.x; c < C; c += 256) gb3[c] = ds3[c];
+    for (int c = threadIdx.x; c < C; c += 256) {
+        float s = 0.f;
+        for (int m = 0; m < hid; ++m) s = fmaf(w1[m * C + c], dh[m], s);
+        dmP[b * C + c] = s / (float)P;
     }
 }
 
@@ -1009,7 +1073,9 @@ __global__ void __launch_bounds__(256) flca_abg_kernel(const float* __restrict__
 
 size_t flca_bwd_scratch_floats(int B, int C, int h, int w) {
     const int P = h * w;
+    const int hid = C / 8 > 8 ? C / 8 : 8;
     return 3 * (size_t)B * C * P + (size_t)B * cdiv(P, 256) * 3 + (size_t)B * chan_sum_nblk(P) * C + 2 * (size_t)B * C + 256 +
+           (size_t)B * (2 * C * hid + hid + C) + 64 +
            gram2_partial_floats(B, C, 2, h, w, 9) + gram2_partial_floats(B, C, 16, h, w, 1) * 3 + (size_t)C * 36 + 64;
 }
 
@@ -1024,11 +1090,17 @@ int launch_flca_backward(const float* feat, const float* guide, const float* xs,
     float* abg = ds + 3 * plane;
     float* dch_part = abg + (size_t)B * nblk * 3;
     float* dmP = dch_part + (size_t)B * dnblk * C;
-    float* gpart = dmP + (size_t)B * C + 64;
+    float* se_contrib = dmP + (size_t)B * C + 64;
+    const size_t n_se = (size_t)2 * C * hid + hid + C;
+    float* gpart = se_contrib + align_up((size_t)B * n_se, 64);
+    // the four squeeze-excite tensors follow each other in the flat gradient buffer (registry order, sizes multiples of 4)
+    RF_CHECK_ARG(grd[7] == grd[6] + (size_t)hid * C && grd[8] == grd[7] + hid && grd[9] == grd[8] + (size_t)C * hid,
+                 "flca backward: the gradients of se.1.weight, se.1.bias, se.3.weight, se.3.bias must be contiguous");
     {
         ProfScope prof(st, "flca_backward(elementwise)", 200.0 * B * C * P, 32.0 * B * C * P);
         flca_dch_kernel<<<dim3((unsigned)dnblk, (unsigned)C, (unsigned)B), 256, 0, st>>>(dz, dz_bstride, xs, dch_part, C, P, dnblk);
-        flca_se_bwd_kernel<<<1, 256, 0, st>>>(pool_partial, pool_nblk, dch_part, dnblk, prm[6], prm[7], prm[8], prm[9], dmP, grd[6], grd[7], grd[8], grd[9], B, C, hid, P);
+        flca_se_bwd_kernel<<<B, 256, 0, st>>>(pool_partial, pool_nblk, dch_part, dnblk, prm[6], prm[7], prm[8], prm[9], dmP, se_contrib, C, hid, P);
+        reduce_partials_kernel<<<red_grid(n_se), 256, 0, st>>>(se_contrib, grd[6], B, n_se, 1);
         FlcaBwdArgs a{feat, guide, dz, dz_bstride, ch, dmP, prm[3], prm[4], prm[5], prm[0], prm[1], prm[2], dfeat, ds, abg, B, C, h, w, nblk, accumulate};
         flca_spatial_bwd_kernel<<<dim3((unsigned)nblk, (unsigned)B), 256, 0, st>>>(a);
         flca_abg_kernel<<<1, 256, 0, st>>>(abg, B * nblk, grd[0], grd[1], grd[2]);

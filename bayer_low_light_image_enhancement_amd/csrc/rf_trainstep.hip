@@ -45,7 +45,7 @@ struct Bump {
 
 struct Stash {      // one Conv_Transformer stage
     const float* in;
-    float *qkvp, *qkv, *partial, *x1, *f1, *f2, *trans, *xs, *cr, *out;
+    float *qkvp, *qkv, *partial, *x1, *f1, *f2, *g, *trans, *xs, *cr, *out;      // g = GELU(f2), written by the same kernel as f2
     float *xraw, *ch, *pool;           // FLCA: xs before the squeeze-excite gate, the gate [B][C], the pooling partial sums
     int nslab, slab;
 };
@@ -82,7 +82,7 @@ int make_train_plan(const rf_handle* h, float* base, int B, int H, int W, TrainP
         const int C = c.dim << lvl, hh = H >> lvl, ww = W >> lvl;
         const size_t U = (size_t)B * C * hh * ww;
         Stash& s = p.st[i];
-        s.qkvp = b.take(3 * U); s.qkv = b.take(3 * U); s.x1 = b.take(U); s.f1 = b.take(hcx * U); s.f2 = b.take(hcx * U);
+        s.qkvp = b.take(3 * U); s.qkv = b.take(3 * U); s.x1 = b.take(U); s.f1 = b.take(hcx * U); s.f2 = b.take(hcx * U); s.g = b.take(hcx * U);
         s.trans = b.take(U); s.xs = b.take(U); s.cr = b.take(U); s.out = b.take(U);
         if (flca) {
             s.xraw = b.take(U); s.ch = b.take((size_t)B * C); s.pool = b.take((size_t)B * flca_nblk(hh, ww) * C);
@@ -162,29 +162,30 @@ int f_conv3x3(const Ctx& c, const float* x, int Cin, const float* w, const float
     return launch_conv3x3(a, c.st);
 }
 
-int f_dw(const Ctx& c, const float* x, const float* w, const float* bias, float* out, int C, int hh, int ww) {
+int f_dw(const Ctx& c, const float* x, const float* w, const float* bias, float* out, int C, int hh, int ww, float* out_gelu = nullptr) {
     DwConvArgs d{};
     d.x = x; d.x_bstride = (int64_t)C * hh * ww; d.out = out; d.out_bstride = (int64_t)C * hh * ww; d.w = w; d.bias = bias;
-    d.B = c.B; d.C = C; d.h = hh; d.w_ = ww; d.gelu = 0;
+    d.B = c.B; d.C = C; d.h = hh; d.w_ = ww; d.gelu = 0; d.out2 = out_gelu;
     return launch_dwconv3x3(d, c.st);
 }
 
 // ---- backward helpers ------------------------------------------------------------------------------------------------
 // dX of a 1x1 conv with raw weight [Cout][K]: conv1x1 with W^T (out: K channels)
-int b_conv1x1_dx(const Ctx& c, const float* dy, int Cout, const float* w, int K, float* dx, int P_, const float* res = nullptr) {
+// (dy_bstride: floats between the images of dy when it is a channel slice of a wider tensor; 0 = contiguous)
+int b_conv1x1_dx(const Ctx& c, const float* dy, int Cout, const float* w, int K, float* dx, int P_, const float* res = nullptr, int64_t dy_bstride = 0) {
     RF_TRY(pack_1x1(w, c.p->wt1, K, Cout, 1, K, c.st));                 // rows = k, cols = co : element W[co][k] at co * K + k
     Conv1x1Args a{};
-    a.x1 = dy; a.C1 = Cout; a.x1_bstride = (int64_t)Cout * P_; a.wp = c.p->wt1;
+    a.x1 = dy; a.C1 = Cout; a.x1_bstride = dy_bstride ? dy_bstride : (int64_t)Cout * P_; a.wp = c.p->wt1;
     a.res = res; a.res_bstride = (int64_t)K * P_;
     a.out = dx; a.out_bstride = (int64_t)K * P_; a.Cout = K; a.B = c.B; a.P = P_; a.w = P_;
     return launch_conv1x1(a, c.st);
 }
 
-// dW [Cout][ld] columns [col0, col0 + Cx) += / = gram2(dy, x);  db = channel sums
-int b_conv1x1_dw(const Ctx& c, const float* dy, int Cout, const float* x, int Cx, float* dW, int ld, int col0, float* db, int hh, int ww) {
-    RF_TRY(launch_gram2(dy, (int64_t)Cout * hh * ww, Cout, x, (int64_t)Cx * hh * ww, Cx, dW + col0, ld, c.p->part, c.B, hh, ww, 1, 0, 0, 0, 0, 1, c.st));
-    if (db && col0 == 0) RF_TRY(launch_chan_sum(dy, (int64_t)Cout * hh * ww, db, c.p->part, c.B, Cout, hh * ww, 1, c.st));
-    return RF_OK;
+// dW [Cout][ld] columns [col0, col0 + Cx) += / = gram2(dy, x);  db = channel sums of dy, taken in the same pass
+int b_conv1x1_dw(const Ctx& c, const float* dy, int Cout, const float* x, int Cx, float* dW, int ld, int col0, float* db, int hh, int ww,
+                 int64_t dy_bstride = 0) {
+    return launch_gram2(dy, dy_bstride ? dy_bstride : (int64_t)Cout * hh * ww, Cout, x, (int64_t)Cx * hh * ww, Cx, dW + col0, ld, c.p->part, c.B, hh, ww,
+                        1, 0, 0, 0, 0, 1, c.st, col0 == 0 ? db : nullptr);
 }
 
 int b_conv3x3_dx(const Ctx& c, const float* dy, int Cout, const float* w, int Cin, float* dx, int hh, int ww) {
@@ -194,9 +195,7 @@ int b_conv3x3_dx(const Ctx& c, const float* dy, int Cout, const float* w, int Ci
 }
 
 int b_conv3x3_dw(const Ctx& c, const float* dy, int Cout, const float* x, int Cin, float* dW, float* db, int hh, int ww) {
-    RF_TRY(launch_gram2(dy, (int64_t)Cout * hh * ww, Cout, x, (int64_t)Cin * hh * ww, Cin, dW, Cin, c.p->part, c.B, hh, ww, 9, 0, 0, 0, 0, 1, c.st));
-    if (db) RF_TRY(launch_chan_sum(dy, (int64_t)Cout * hh * ww, db, c.p->part, c.B, Cout, hh * ww, 1, c.st));
-    return RF_OK;
+    return launch_gram2(dy, (int64_t)Cout * hh * ww, Cout, x, (int64_t)Cin * hh * ww, Cin, dW, Cin, c.p->part, c.B, hh, ww, 9, 0, 0, 0, 0, 1, c.st, db);
 }
 
 int b_dw(const Ctx& c, const float* dy, const float* x, const float* w, float* dx, float* dW, float* db, int C, int hh, int ww) {
@@ -354,7 +353,6 @@ int stage_forward(const Ctx& c, int i, int lvl, const float* in, int H, int W) {
     const std::string pre = "conv_tran" + std::to_string(i) + ".", t = pre + "Transformer.";
     Stash& s = c.p->st[i];
     s.in = in;
-    const size_t U = (size_t)c.B * C * Pn;
     RF_TRY(f_conv1x1(c, in, C, nullptr, 0, P(h, t + "attn.qkv.weight"), P(h, t + "attn.qkv.bias"), P(h, t + "norm1.body.weight"),
                      P(h, t + "norm1.body.bias"), nullptr, s.qkvp, 3 * C, Pn));
     RF_TRY(f_dw(c, s.qkvp, P(h, t + "attn.qkv_dwconv.weight"), P(h, t + "attn.qkv_dwconv.bias"), s.qkv, 3 * C, hh, ww));
@@ -374,9 +372,8 @@ int stage_forward(const Ctx& c, int i, int lvl, const float* in, int H, int W) {
     }
     RF_TRY(f_conv1x1(c, s.x1, C, nullptr, 0, P(h, t + "ffn.pointwise1.weight"), P(h, t + "ffn.pointwise1.bias"), P(h, t + "norm2.body.weight"),
                      P(h, t + "norm2.body.bias"), nullptr, s.f1, hc, Pn));
-    RF_TRY(f_dw(c, s.f1, P(h, t + "ffn.depthwise.weight"), P(h, t + "ffn.depthwise.bias"), s.f2, hc, hh, ww));
-    RF_TRY(launch_ewise(s.f2, nullptr, c.p->tA, (size_t)c.B * hc * Pn, 3, 0.f, c.st));                  // g = gelu(f2)
-    RF_TRY(f_conv1x1(c, c.p->tA, hc, nullptr, 0, P(h, t + "ffn.pointwise2.weight"), P(h, t + "ffn.pointwise2.bias"), nullptr, nullptr, s.x1, s.trans, C, Pn));
+    RF_TRY(f_dw(c, s.f1, P(h, t + "ffn.depthwise.weight"), P(h, t + "ffn.depthwise.bias"), s.f2, hc, hh, ww, s.g));   // f2 and g = gelu(f2)
+    RF_TRY(f_conv1x1(c, s.g, hc, nullptr, 0, P(h, t + "ffn.pointwise2.weight"), P(h, t + "ffn.pointwise2.bias"), nullptr, nullptr, s.x1, s.trans, C, Pn));
     if (cfg.variant == RF_VARIANT_FLCA) {
         const std::string f = pre + "FLCA.";
         FlcaSpatialArgs sa{};
@@ -388,8 +385,7 @@ int stage_forward(const Ctx& c, int i, int lvl, const float* in, int H, int W) {
         const int hid = C / 8 > 8 ? C / 8 : 8;
         RF_TRY(launch_flca_se(s.pool, sa.nblk, Pn, P(h, f + "se.1.weight"), P(h, f + "se.1.bias"), P(h, f + "se.3.weight"), P(h, f + "se.3.bias"),
                               hid, s.ch, c.B, C, c.st));
-        RF_TRY(check_hip(hipMemcpyAsync(s.xs, s.xraw, U * 4, hipMemcpyDeviceToDevice, c.st), "copy"));
-        RF_TRY(launch_scale_channels(s.xs, s.ch, c.B, C, Pn, c.st));                                    // xs = branch output z
+        RF_TRY(launch_scale_channels_to(s.xraw, s.xs, s.ch, c.B, C, Pn, c.st));                         // xs = branch output z
     } else {
         RF_TRY(f_conv3x3(c, in, C, P(h, pre + "conv.weight"), P(h, pre + "conv.bias"), s.xs, C, hh, ww, cfg.branch_lrelu ? 1 : 0, 0));
     }
@@ -415,8 +411,14 @@ int stage_backward(const Ctx& c, int i, int lvl, float* dout, float* din, int H,
     RF_TRY(b_conv1x1_dw(c, tB, C, s.xs, C, c.G(pre + "channel_reduce.weight"), 2 * C, 0, c.G(pre + "channel_reduce.bias"), hh, ww));
     RF_TRY(b_conv1x1_dw(c, tB, C, s.trans, C, c.G(pre + "channel_reduce.weight"), 2 * C, C, nullptr, hh, ww));
     RF_TRY(b_conv1x1_dx(c, tB, C, P(h, pre + "channel_reduce.weight"), 2 * C, tC, Pn));               // tC = [dxs ; dtrans] per image
-    // the two halves as contiguous tensors: tA = dxs, tD = dtrans
-    RF_TRY(launch_split_halves(tC, tA, tD, c.B, C, Pn, c.st));
+    // dxs and dtrans are read in place as channel slices of tC (image stride 2C Pn) by the kernels that take a stride; only the
+    // plain variant's element-wise LeakyReLU adjoint needs contiguous halves (tA = dxs, tD = dtrans)
+    const float* dtr = tC + (size_t)C * Pn;
+    int64_t dtr_bs = (int64_t)2 * C * Pn;
+    if (cfg.variant != RF_VARIANT_FLCA || !ln_bwd_fused_shape(C, Pn)) {
+        RF_TRY(launch_split_halves(tC, tA, tD, c.B, C, Pn, c.st));
+        dtr = tD; dtr_bs = (int64_t)C * Pn;
+    }
     if (cfg.variant == RF_VARIANT_FLCA) {
         const std::string f = pre + "FLCA.";
         const char* names[10] = {"alpha", "beta", "gamma", "low_attn.0.weight", "high_attn.0.weight", "chroma_attn.0.weight",
@@ -424,7 +426,7 @@ int stage_backward(const Ctx& c, int i, int lvl, float* dout, float* din, int H,
         const float* prm[10];
         float* grd[10];
         for (int k = 0; k < 10; ++k) { prm[k] = P(h, f + names[k]); grd[k] = c.G(f + names[k]); }
-        RF_TRY(launch_flca_backward(s.in, c.p->guide[lvl], s.xraw, tA, (int64_t)C * Pn, s.ch, s.pool, flca_nblk(hh, ww), prm, grd, din, 0,
+        RF_TRY(launch_flca_backward(s.in, c.p->guide[lvl], s.xraw, dtr == tD ? tA : tC, dtr == tD ? (int64_t)C * Pn : (int64_t)2 * C * Pn, s.ch, s.pool, flca_nblk(hh, ww), prm, grd, din, 0,
                                     c.p->flca_scr, c.B, C, hh, ww, c.st));                             // din = branch part
     } else {
         // conv branch
@@ -432,18 +434,19 @@ int stage_backward(const Ctx& c, int i, int lvl, float* dout, float* din, int H,
         RF_TRY(b_conv3x3_dw(c, tA, C, s.in, C, c.G(pre + "conv.weight"), c.G(pre + "conv.bias"), hh, ww));
         RF_TRY(b_conv3x3_dx(c, tA, C, P(h, pre + "conv.weight"), C, din, hh, ww));                    // din = branch part
     }
-    // FFN:  trans = x1 + pw2(gelu(dw(pw1(LN2(x1)))))          tD = dtrans (also the residual part of dx1)
-    RF_TRY(launch_ewise(s.f2, nullptr, tA, (size_t)c.B * hc * Pn, 3, 0.f, c.st));                     // tA = g
-    RF_TRY(b_conv1x1_dw(c, tD, C, tA, hc, c.G(t + "ffn.pointwise2.weight"), hc, 0, c.G(t + "ffn.pointwise2.bias"), hh, ww));
-    RF_TRY(b_conv1x1_dx(c, tD, C, P(h, t + "ffn.pointwise2.weight"), hc, tB, Pn));                    // tB = dg
+    // FFN:  trans = x1 + pw2(gelu(dw(pw1(LN2(x1)))))          dtr = dtrans (also the residual part of dx1)
+    RF_TRY(b_conv1x1_dw(c, dtr, C, s.g, hc, c.G(t + "ffn.pointwise2.weight"), hc, 0, c.G(t + "ffn.pointwise2.bias"), hh, ww, dtr_bs));
+    RF_TRY(b_conv1x1_dx(c, dtr, C, P(h, t + "ffn.pointwise2.weight"), hc, tB, Pn, nullptr, dtr_bs));  // tB = dg
     RF_TRY(launch_ewise(tB, s.f2, tB, (size_t)c.B * hc * Pn, 1, 0.f, c.st));                          // tB = df2
     RF_TRY(b_dw(c, tB, s.f1, P(h, t + "ffn.depthwise.weight"), tA, c.G(t + "ffn.depthwise.weight"), c.G(t + "ffn.depthwise.bias"), hc, hh, ww));   // tA = df1
     RF_TRY(launch_layernorm2d(s.x1, tB, P(h, t + "norm2.body.weight"), P(h, t + "norm2.body.bias"), 1e-5f, c.B, C, Pn, c.st));   // tB = LN2(x1)
     RF_TRY(b_conv1x1_dw(c, tA, hc, tB, C, c.G(t + "ffn.pointwise1.weight"), C, 0, c.G(t + "ffn.pointwise1.bias"), hh, ww));
     RF_TRY(b_conv1x1_dx(c, tA, hc, P(h, t + "ffn.pointwise1.weight"), C, tB, Pn));                    // tB = d LN2 out
-    RF_TRY(launch_ln_bwd(s.x1, tB, P(h, t + "norm2.body.weight"), tD, c.G(t + "norm2.body.weight"), c.p->part, c.B, C, Pn, 1e-5f, 1, 1, c.st));   // tD = dx1
-    // attention:  x1 = in + W_out (A v) + b
-    RF_TRY(launch_ewise(din, tD, din, U, 0, 0.f, c.st));                                              // residual: din += dx1
+    if (dtr == tD)
+        RF_TRY(launch_ln_bwd(s.x1, tB, P(h, t + "norm2.body.weight"), tD, c.G(t + "norm2.body.weight"), c.p->part, c.B, C, Pn, 1e-5f, 1, 1, c.st));
+    else       // tD = dx1 = dtrans + (LayerNorm adjoint), dtrans read in place
+        RF_TRY(launch_ln_bwd(s.x1, tB, P(h, t + "norm2.body.weight"), tD, c.G(t + "norm2.body.weight"), c.p->part, c.B, C, Pn, 1e-5f, 0, 1, c.st, dtr, dtr_bs));
+    // attention:  x1 = in + W_out (A v) + b          (the residual din += dx1 rides on the last kernel of the stage)
     const size_t CC = (size_t)C * C;
     const size_t per = 3 * CC + packed1x1_floats(2 * C, 2 * C) + 2 * packed1x1_floats(C, C);
     RF_TRY(check_hip(hipMemsetAsync(c.p->small, 0, (c.B * (per + 64)) * sizeof(float), c.st), "memset"));
@@ -476,8 +479,9 @@ int stage_backward(const Ctx& c, int i, int lvl, float* dout, float* din, int H,
     RF_TRY(launch_layernorm2d(s.in, tB, P(h, t + "norm1.body.weight"), P(h, t + "norm1.body.bias"), 1e-5f, c.B, C, Pn, c.st));   // tB = LN1(in)
     RF_TRY(b_conv1x1_dw(c, tA, 3 * C, tB, C, c.G(t + "attn.qkv.weight"), C, 0, c.G(t + "attn.qkv.bias"), hh, ww));
     RF_TRY(b_conv1x1_dx(c, tA, 3 * C, P(h, t + "attn.qkv.weight"), C, tB, Pn));                       // tB = d LN1 out
-    RF_TRY(launch_ln_bwd(s.in, tB, P(h, t + "norm1.body.weight"), din, c.G(t + "norm1.body.weight"), c.p->part, c.B, C, Pn, 1e-5f, 1, 1, c.st));
-    (void)tE;
+    // din (branch part) += dx1 (residual of x1 = in + attention) + (LayerNorm adjoint)
+    RF_TRY(launch_ln_bwd(s.in, tB, P(h, t + "norm1.body.weight"), din, c.G(t + "norm1.body.weight"), c.p->part, c.B, C, Pn, 1e-5f, 1, 1, c.st, tD, (int64_t)C * Pn));
+    (void)tE; (void)U;
     return RF_OK;
 }
 

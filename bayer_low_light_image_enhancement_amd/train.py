@@ -134,7 +134,7 @@ class Trainer:
             raise RuntimeError(f"ground truth must be {(b, self.model.out_channels, h, w)}, got {tuple(gt.shape)}")
         H, W = h // 2, w // 2
         with torch.cuda.device(x.device):
-            self.model._sync_params(self.state, x.device)      # registers the (flat-buffer) pointers with the handle
+            self.model._sync_params(self.state, x.device, pack=False)   # the (flat-buffer) pointers, once: rf_train_step reads raw weights
             sz = C.c_size_t()
             _lib.check(lib.rf_train_workspace_bytes(self.state.handle, b, H, W, C.byref(sz)), "rf_train_workspace_bytes")
             if self.workspace is None or self.workspace.numel() < sz.value:

@@ -308,3 +308,32 @@ def test_config4_tiled_vs_untiled_psnr_matches_the_reference_measurement(device)
             out = tiling.forward_tiled(m, x, tiles)
             mse = float(((out - whole).double() ** 2).mean())
             assert abs(10 * np.log10(1.0 / mse) - g["overlap"][str(ov)]["psnr_db"]) <= 0.05
+
+
+@pytest.mark.gpu
+def test_forward_captures_into_a_hip_graph(device):
+    """rf_forward forks its branch stream from the caller's stream with events only, so a stream capture takes the whole forward
+    (both streams): the replayed graph returns the eager result bit for bit, also on new input written into the captured buffer."""
+    dim, seed = 32, 91
+    m, sd = build(dim, seed, device)
+    x = torch.from_numpy(synth.bayer_mosaic(seed, 1, 128, 160)).to(device)
+    x2 = torch.from_numpy(synth.bayer_mosaic(seed + 1, 1, 128, 160)).to(device)
+    with torch.no_grad():
+        eager = m(x).clone()
+        eager2 = m(x2).clone()
+        s = torch.cuda.Stream()
+        s.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(s):
+            m(x)
+        torch.cuda.current_stream().wait_stream(s)
+        buf = x.clone()
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            y = m(buf)
+        g.replay()
+        torch.cuda.synchronize()
+        assert torch.equal(y, eager)
+        buf.copy_(x2)
+        g.replay()
+        torch.cuda.synchronize()
+        assert torch.equal(y, eager2)
