@@ -978,52 +978,114 @@ __global__ void __launch_bounds__(256) flca_spatial_bwd_kernel(FlcaBwdArgs a) {
         a.abg_partial[(b * a.nblk + blk) * 3 + threadIdx.x] = (red[threadIdx.x][0] + red[threadIdx.x][1]) + (red[threadIdx.x][2] + red[threadIdx.x][3]);
 }
 
-// Tap sums of the three gate convolutions in ONE pass over ds (they had been three gram2<9> launches whose 16 x 16 tiles held
-// one or two useful B rows: 21 launches and 2.5 ms of the step).  G[c][col] = sum_p ds_k[c][p] * plane_k[p + tap], a contraction over
-// pixels with the TAPS as the B rows: lane (r, kq) of the B operand loads tap r of its plane at the lane's 4 pixels (the guidance
-// planes are 4 x P floats: cache resident), the A operands are 16-byte rows of ds_low / ds_high / ds_chr.  Four accumulator
-// tiles per A tile: low x plane 0, high x plane 1, chroma x plane 2, chroma x plane 3 (columns 0-8 = the 3 x 3 window).
-// partial[(slab * C + c) * 36 + {low 0-8, high 9-17, chroma 18-35}], slabs reduced in order by reduce_partials_kernel.
-__global__ void __launch_bounds__(256) flca_taps_kernel(const float* __restrict__ ds, size_t plane_stride, const float* __restrict__ guide,
-                                                        float* __restrict__ partial, int C, int h, int w, int slab_px, int slabs_per_image) {
+// Spatial part and tap sums in ONE kernel (w % 4 == 0): the element-wise kernel above writes the three ds tensors for a tap-sum pass to
+// read back (6 of the 9 streams of the pair).  Here a lane owns channel 16 ti + r and the 4 pixels of its pixel group kq -- the
+// A-operand layout of the tap contraction below -- recomputes the three gates of its channel at those pixels from the guidance
+// neighbourhood (36 weights of the channel in registers), writes dfeat, and feeds ds_low / ds_high / ds_chr straight into the
+// MFMAs whose B rows are the TAPS: G[c][col] = sum_p ds_k[c][p] * plane_k[p + tap] is a contraction over pixels; lane (r, kq) of
+// the B operand loads tap r of its plane at the lane's 4 pixels, four accumulator tiles per A tile: low x plane 0, high x plane 1,
+// chroma x plane 2, chroma x plane 3 (columns 0-8 = the 3 x 3 window).  dz and feat are read once, dfeat written once, nothing
+// else touches HBM (the guidance planes are cache resident).
+// partial[(slab * C + c) * 36 + {low 0-8, high 9-17, chroma 18-35}], slabs reduced in order by reduce_partials_kernel;
+// abg_partial[(slab * gridDim.y + ti) * 3 + k].
+__device__ __forceinline__ float fsig(float x) { return __builtin_amdgcn_rcpf(1.0f + __expf(-x)); }
+
+__global__ void __launch_bounds__(256) flca_bwd_fused_kernel(FlcaBwdArgs a, float* __restrict__ partial, int slab_px, int slabs_per_image) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int r = lane & 15, kq = lane >> 4;
     const int slab = blockIdx.x, ti = blockIdx.y;
     const int img = slab / slabs_per_image, sl = slab - img * slabs_per_image;
-    const int P = h * w;
+    const int h = a.h, w = a.w, P = h * w, C = a.C;
     const int n_lo = sl * slab_px, n_hi = (n_lo + slab_px < P) ? n_lo + slab_px : P;
-    const int ch = (16 * ti + r < C) ? 16 * ti + r : C - 1;
-    const float* a0 = ds + ((size_t)img * C + ch) * P;                 // ds_low row of this lane's channel (A operand)
-    const float* gpl = guide + (size_t)img * 4 * P;
-    const int dy = r < 9 ? r / 3 - 1 : 0, dx = r < 9 ? r % 3 - 1 : 0;  // this lane's tap (B operand rows 9-15 are zero)
+    const bool cvalid = 16 * ti + r < C;
+    const int c = cvalid ? 16 * ti + r : C - 1;
+    float wl[9], wh[9], wc[18];
+#pragma unroll
+    for (int t = 0; t < 9; ++t) { wl[t] = a.w_low[c * 9 + t]; wh[t] = a.w_high[c * 9 + t]; wc[t] = a.w_chr[c * 18 + t]; wc[9 + t] = a.w_chr[c * 18 + 9 + t]; }
+    const float al = *a.alpha, be = *a.beta, ga = *a.gamma;
+    const float chv = a.ch[(size_t)img * C + c], dm = a.dmP[(size_t)img * C + c];
+    const float* dzr = a.dz + (size_t)img * a.dz_bstride + (size_t)c * P;
+    const float* fr = a.feat + ((size_t)img * C + c) * P;
+    float* dfr = a.dfeat + ((size_t)img * C + c) * P;
+    const float* gpl = a.guide + (size_t)img * 4 * P;
+    const int tdy = r < 9 ? r / 3 - 1 : 0, tdx = r < 9 ? r % 3 - 1 : 0;      // this lane's tap (B operand rows 9-15 are zero)
     f32x4 acc[4];
 #pragma unroll
     for (int t = 0; t < 4; ++t) acc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    float sa = 0.f, sb = 0.f, sg = 0.f;
     for (int n0 = n_lo + wave * 16; n0 < n_hi; n0 += 64) {
         const int nn = n0 + 4 * kq;
         const bool ok = nn < n_hi;
         const int n = ok ? nn : n_lo;
-        const float4 al = ld4(a0 + n), ah = ld4(a0 + plane_stride + n), ac = ld4(a0 + 2 * plane_stride + n);
-        const int y = n / w, x = n - y * w, yy = y + dy;
-        const bool rowok = ok && r < 9 && yy >= 0 && yy < h;
+        const int y = n / w, x = n - y * w;
+        const float4 dz4 = ld4(dzr + n), f4 = ld4(fr + n);
+        // B operand: this lane's tap of the four planes at the lane's 4 pixels
         float bv[4][4];
+        {
+            const int yy = y + tdy;
+            const bool rowok = ok && r < 9 && yy >= 0 && yy < h;
 #pragma unroll
-        for (int m = 0; m < 4; ++m) {
-            const int xx = x + m + dx;
-            const bool in = rowok && xx >= 0 && xx < w;
-            const size_t off = in ? (size_t)yy * w + xx : 0;
+            for (int m = 0; m < 4; ++m) {
+                const int xx = x + m + tdx;
+                const bool in = rowok && xx >= 0 && xx < w;
+                const size_t off = in ? (size_t)yy * w + xx : 0;
 #pragma unroll
-            for (int pl = 0; pl < 4; ++pl) { const float v = gpl[(size_t)pl * P + off]; bv[pl][m] = in ? v : 0.f; }
+                for (int pl = 0; pl < 4; ++pl) { const float v = gpl[(size_t)pl * P + off]; bv[pl][m] = in ? v : 0.f; }
+            }
         }
-        const float aL[4] = {ok ? al.x : 0.f, ok ? al.y : 0.f, ok ? al.z : 0.f, ok ? al.w : 0.f};
-        const float aH[4] = {ok ? ah.x : 0.f, ok ? ah.y : 0.f, ok ? ah.z : 0.f, ok ? ah.w : 0.f};
-        const float aC[4] = {ok ? ac.x : 0.f, ok ? ac.y : 0.f, ok ? ac.z : 0.f, ok ? ac.w : 0.f};
+        // gates of the lane's channel at its 4 pixels: pre-activations from the 3 x 6 neighbourhood of each plane
+        float s_l[4] = {0.f, 0.f, 0.f, 0.f}, s_h[4] = {0.f, 0.f, 0.f, 0.f}, s_c[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int dy = 0; dy < 3; ++dy) {
+            const int yy = y + dy - 1;
+            const bool rok = yy >= 0 && yy < h;
+            const size_t rowoff = (size_t)(rok ? yy : 0) * w + x;
+            float nb[4][6];
+#pragma unroll
+            for (int pl = 0; pl < 4; ++pl) {
+                const float* row = gpl + (size_t)pl * P + rowoff;
+                const float4 t = ld4(row);
+                const float lft = row[x > 0 ? -1 : 0], rgt = row[x + 4 < w ? 4 : 0];
+                nb[pl][0] = (rok && x > 0) ? lft : 0.f;
+                nb[pl][1] = rok ? t.x : 0.f; nb[pl][2] = rok ? t.y : 0.f; nb[pl][3] = rok ? t.z : 0.f; nb[pl][4] = rok ? t.w : 0.f;
+                nb[pl][5] = (rok && x + 4 < w) ? rgt : 0.f;
+            }
+#pragma unroll
+            for (int dx = 0; dx < 3; ++dx) {
+                const float k0 = wl[dy * 3 + dx], k1 = wh[dy * 3 + dx], k2 = wc[dy * 3 + dx], k3 = wc[9 + dy * 3 + dx];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    s_l[q] = fmaf(k0, nb[0][q + dx], s_l[q]);
+                    s_h[q] = fmaf(k1, nb[1][q + dx], s_h[q]);
+                    s_c[q] = fmaf(k3, nb[3][q + dx], fmaf(k2, nb[2][q + dx], s_c[q]));
+                }
+            }
+        }
+        const float dzv[4] = {dz4.x, dz4.y, dz4.z, dz4.w}, fv[4] = {f4.x, f4.y, f4.z, f4.w};
+        const float live = (ok && cvalid) ? 1.0f : 0.f;
+        float dsl[4], dsh[4], dsc[4], df[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const float a_l = fsig(s_l[q]), a_h = 2.0f * fsig(2.0f * s_h[q]) - 1.0f, a_c = fsig(s_c[q]);
+            const float dxs = live * fmaf(dzv[q], chv, dm);
+            df[q] = dxs * (1.0f + al * a_l + be * a_h + ga * a_c);
+            const float dS = dxs * fv[q];
+            dsl[q] = al * dS * a_l * (1.0f - a_l);
+            dsh[q] = be * dS * (1.0f - a_h * a_h);
+            dsc[q] = ga * dS * a_c * (1.0f - a_c);
+            sa = fmaf(dS, a_l, sa); sb = fmaf(dS, a_h, sb); sg = fmaf(dS, a_c, sg);
+        }
+        if (ok && cvalid) {
+            float4 o = make_float4(df[0], df[1], df[2], df[3]);
+            if (a.accumulate) { const float4 p = ld4(dfr + n); o.x += p.x; o.y += p.y; o.z += p.z; o.w += p.w; }
+            *reinterpret_cast<float4*>(dfr + n) = o;
+        }
 #pragma unroll
         for (int m = 0; m < 4; ++m) {
-            acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(aL[m], bv[0][m], acc[0], 0, 0, 0);
-            acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(aH[m], bv[1][m], acc[1], 0, 0, 0);
-            acc[2] = __builtin_amdgcn_mfma_f32_16x16x4f32(aC[m], bv[2][m], acc[2], 0, 0, 0);
-            acc[3] = __builtin_amdgcn_mfma_f32_16x16x4f32(aC[m], bv[3][m], acc[3], 0, 0, 0);
+            acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(dsl[m], bv[0][m], acc[0], 0, 0, 0);
+            acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(dsh[m], bv[1][m], acc[1], 0, 0, 0);
+            acc[2] = __builtin_amdgcn_mfma_f32_16x16x4f32(dsc[m], bv[2][m], acc[2], 0, 0, 0);
+            acc[3] = __builtin_amdgcn_mfma_f32_16x16x4f32(dsc[m], bv[3][m], acc[3], 0, 0, 0);
         }
     }
     __shared__ float red[4][16][17];
@@ -1038,6 +1100,15 @@ __global__ void __launch_bounds__(256) flca_taps_kernel(const float* __restrict_
         if (gi < C && jj < 9)
             partial[((size_t)slab * C + gi) * 36 + 9 * t + jj] = ((red[0][i][jj] + red[1][i][jj]) + red[2][i][jj]) + red[3][i][jj];
     }
+    // dalpha, dbeta, dgamma: wave butterflies, then the four waves in order
+    __syncthreads();
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { sa += __shfl_xor(sa, o); sb += __shfl_xor(sb, o); sg += __shfl_xor(sg, o); }
+    if (lane == 0) { red[0][0][wave] = sa; red[0][1][wave] = sb; red[0][2][wave] = sg; }
+    __syncthreads();
+    if (threadIdx.x < 3)
+        a.abg_partial[((size_t)slab * gridDim.y + ti) * 3 + threadIdx.x] =
+            (red[0][threadIdx.x][0] + red[0][threadIdx.x][1]) + (red[0][threadIdx.x][2] + red[0][threadIdx.x][3]);
 }
 
 // the 36 tap sums of a channel -> the three weight gradients: low [C][9], high [C][9], chroma [C][2][9]
@@ -1096,27 +1167,36 @@ int launch_flca_backward(const float* feat, const float* guide, const float* xs,
     // the four squeeze-excite tensors follow each other in the flat gradient buffer (registry order, sizes multiples of 4)
     RF_CHECK_ARG(grd[7] == grd[6] + (size_t)hid * C && grd[8] == grd[7] + hid && grd[9] == grd[8] + (size_t)C * hid,
                  "flca backward: the gradients of se.1.weight, se.1.bias, se.3.weight, se.3.bias must be contiguous");
-    {
-        ProfScope prof(st, "flca_backward(elementwise)", 200.0 * B * C * P, 32.0 * B * C * P);
+    // squeeze-excite part: dch -> per-image MLP adjoint -> dm, the four se gradients
+    auto se_part = [&]() -> int {
         flca_dch_kernel<<<dim3((unsigned)dnblk, (unsigned)C, (unsigned)B), 256, 0, st>>>(dz, dz_bstride, xs, dch_part, C, P, dnblk);
         flca_se_bwd_kernel<<<B, 256, 0, st>>>(pool_partial, pool_nblk, dch_part, dnblk, prm[6], prm[7], prm[8], prm[9], dmP, se_contrib, C, hid, P);
         reduce_partials_kernel<<<red_grid(n_se), 256, 0, st>>>(se_contrib, grd[6], B, n_se, 1);
+        return check_launch("flca_backward (squeeze-excite)");
+    };
+    if (w % 4 == 0 && aligned16(dz) && dz_bstride % 4 == 0 && aligned16(feat) && aligned16(dfeat) && aligned16(guide)) {
+        // spatial part + tap sums in one kernel; abg partials live in the (unused) ds area
+        int slab_px, per_image;
+        gram2_slabs(B, P, cdiv(C, 16), &slab_px, &per_image);
+        const int nslab = B * per_image, nti = cdiv(C, 16);
+        float* sums = gpart + (size_t)nslab * C * 36;
+        float* abg2 = ds;
+        ProfScope prof(st, "flca_backward(fused)", 2.0 * 36 * (double)B * C * P + 200.0 * B * C * P, 12.0 * (double)B * C * P + 8.0 * B * C * P);
+        if (int rc = se_part()) return rc;
+        FlcaBwdArgs a{feat, guide, dz, dz_bstride, ch, dmP, prm[3], prm[4], prm[5], prm[0], prm[1], prm[2], dfeat, nullptr, abg2, B, C, h, w, nblk, accumulate};
+        flca_bwd_fused_kernel<<<dim3((unsigned)nslab, (unsigned)nti), 256, 0, st>>>(a, gpart, slab_px, per_image);
+        flca_abg_kernel<<<1, 256, 0, st>>>(abg2, nslab * nti, grd[0], grd[1], grd[2]);
+        reduce_partials_kernel<<<red_grid((size_t)C * 36), 256, 0, st>>>(gpart, sums, nslab, (size_t)C * 36, 0);
+        flca_taps_scatter_kernel<<<cdiv(C * 36, 256), 256, 0, st>>>(sums, grd[3], grd[4], grd[5], C);
+        return check_launch("flca_backward (fused)");
+    }
+    {
+        ProfScope prof(st, "flca_backward(elementwise)", 200.0 * B * C * P, 32.0 * B * C * P);
+        if (int rc = se_part()) return rc;
         FlcaBwdArgs a{feat, guide, dz, dz_bstride, ch, dmP, prm[3], prm[4], prm[5], prm[0], prm[1], prm[2], dfeat, ds, abg, B, C, h, w, nblk, accumulate};
         flca_spatial_bwd_kernel<<<dim3((unsigned)nblk, (unsigned)B), 256, 0, st>>>(a);
         flca_abg_kernel<<<1, 256, 0, st>>>(abg, B * nblk, grd[0], grd[1], grd[2]);
         if (int rc = check_launch("flca_backward")) return rc;
-    }
-    // tap sums = 3x3 weight gradients with the guidance planes as (1- or 2-channel) inputs: one pass over ds
-    if (w % 4 == 0) {
-        int slab_px, per_image;
-        gram2_slabs(B, P, cdiv(C, 16), &slab_px, &per_image);
-        const int nslab = B * per_image;
-        float* sums = gpart + (size_t)nslab * C * 36;
-        ProfScope prof(st, "flca_taps_kernel", 2.0 * 36 * (double)B * C * P, 12.0 * (double)B * C * P);
-        flca_taps_kernel<<<dim3((unsigned)nslab, (unsigned)cdiv(C, 16)), 256, 0, st>>>(ds, plane, guide, gpart, C, h, w, slab_px, per_image);
-        reduce_partials_kernel<<<red_grid((size_t)C * 36), 256, 0, st>>>(gpart, sums, nslab, (size_t)C * 36, 0);
-        flca_taps_scatter_kernel<<<cdiv(C * 36, 256), 256, 0, st>>>(sums, grd[3], grd[4], grd[5], C);
-        return check_launch("flca_taps");
     }
     if (int rc = launch_gram2(ds, (int64_t)C * P, C, guide, (int64_t)4 * P, 1, grd[3], 1, gpart, B, h, w, 9, 0, 0, 0, 0, 1, st)) return rc;
     if (int rc = launch_gram2(ds + plane, (int64_t)C * P, C, guide + P, (int64_t)4 * P, 1, grd[4], 1, gpart, B, h, w, 9, 0, 0, 0, 0, 1, st)) return rc;
