@@ -143,6 +143,19 @@ int pack_1x1(const float* w, float* packed, int Cout, int K, int64_t row_stride,
 int pack_3x3(const float* w, float* packed, int Cout, int Cin, hipStream_t st);
 int pack_convT(const float* w, float* packed, int Cin, int Cout, hipStream_t st);
 
+// ---- batched weight packing (rf_pack.hip; the training step packs every weight form it needs in a few launches)
+struct PackDesc {
+    const float* src; float* dst;
+    int kind;              // 0: 1x1 generic strides, 1: 3x3 Winograd generic strides (+ tap flip), 2: depthwise taps flipped
+    int rows, cols;        // of the packed matrix (rows = its output channels)
+    int64_t rs, cs;        // floats between rows / columns of src
+    int flip;
+};
+constexpr int kPackBatch = 48;
+struct PackBatch { PackDesc d[kPackBatch]; };
+size_t pack_desc_floats(const PackDesc& d);
+int launch_pack_batch(const PackDesc* d, int n, hipStream_t st);
+
 // ---- decoder step ConvTranspose2d(2C,C,2,2) + cat skip + Conv2d(2C,C,1) on composed weights (rf_upcat.hip)
 size_t upcat_packed_floats(int C);
 int pack_upcat(const float* up_w, const float* up_b, const float* cr_w, const float* cr_b, float* packed, int C, hipStream_t st);

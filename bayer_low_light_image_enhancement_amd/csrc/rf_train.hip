@@ -42,7 +42,7 @@ struct Gram2Args {
 // is -- are accumulated per lane on the way (4 NA additions beside 16 NA TJ MFMAs) instead of by a second pass over dOut.
 template <int NTAP, int NA, int TJ>
 __global__ void __launch_bounds__(256) gram2_kernel(Gram2Args g) {
-    static_assert(NTAP == 1 || (NA == 1 && TJ == 1), "several A / B tiles only in the single-tap form");
+    static_assert(NTAP == 1 || TJ == 1, "several B tiles only in the single-tap form");
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int r = lane & 15, kq = lane >> 4;
     const int slab = blockIdx.x, ti = blockIdx.y, tjg = blockIdx.z;
@@ -61,7 +61,7 @@ __global__ void __launch_bounds__(256) gram2_kernel(Gram2Args g) {
         const int jb = 16 * (tjg * TJ + t) + r;
         brow[t] = g.b + (size_t)img * g.b_bstride + (size_t)(jb < g.Cb ? jb : g.Cb - 1) * P;
     }
-    f32x4 acc[NTAP * NA][TJ];       // [tap] (NA = 1) or [A tile] (NTAP = 1)
+    f32x4 acc[NTAP * NA][TJ];       // [tap * NA + A tile]
 #pragma unroll
     for (int k = 0; k < NTAP * NA; ++k)
 #pragma unroll
@@ -128,8 +128,10 @@ __global__ void __launch_bounds__(256) gram2_kernel(Gram2Args g) {
 #pragma unroll
                 for (int k = 0; k < 9; ++k)
 #pragma unroll
-                    for (int m = 0; m < 4; ++m)
-                        acc[k][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(aa[0][m], v[k / 3][m + k % 3], acc[k][t], 0, 0, 0);
+                    for (int u = 0; u < NA; ++u)
+#pragma unroll
+                        for (int m = 0; m < 4; ++m)
+                            acc[k * NA + u][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(aa[u][m], v[k / 3][m + k % 3], acc[k * NA + u][t], 0, 0, 0);
             }
         }
     };
@@ -156,7 +158,7 @@ __global__ void __launch_bounds__(256) gram2_kernel(Gram2Args g) {
             for (int q = 0; q < 4; ++q) red[wave][4 * kq + q][r] = acc[k][t][q];
             __syncthreads();
             const int i = threadIdx.x >> 4, j = threadIdx.x & 15;       // 256 threads = the 16 x 16 tile
-            const int tap = NTAP == 1 ? 0 : k, u = NTAP == 1 ? k : 0;
+            const int tap = k / NA, u = k % NA;
             const int gi = 16 * (ti * NA + u) + i, gj = 16 * (tjg * TJ + t) + j;
             if (gi < g.Ca && gj < g.Cb)
                 g.partial[(((size_t)slab * NTAP + tap) * g.Ca + gi) * g.Cb + gj] = ((red[0][i][j] + red[1][i][j]) + red[2][i][j]) + red[3][i][j];
@@ -627,7 +629,8 @@ static void gram2_slabs(int B, int P, int tiles, int* slab_px, int* per_image) {
 
 // A tiles per workgroup of the single-tap form: all of Ca when that is at most 6 tiles, else the divisor that leaves fewest groups
 static int gram2_na(int Ca, int ntap) {
-    if (ntap != 1) return 1;
+    // 3x3 form: two A tiles share the nine shifted B operands of a step (the row loads, masks and selects are per B tile)
+    if (ntap != 1) return cdiv(Ca, 16) % 2 == 0 ? 2 : 1;
     const int nt = cdiv(Ca, 16);
     if (nt <= 4 || nt == 6) return nt;
     if (nt % 6 == 0) return 6;
@@ -663,7 +666,8 @@ int launch_gram2(const float* a, int64_t a_bstride, int Ca, const float* b, int6
     const dim3 grid1((unsigned)nslab, (unsigned)cdiv(Ca, 16 * na), (unsigned)cdiv(Cb, 16 * tj));
 #define RF_G2(NA_, TJ_) gram2_kernel<1, NA_, TJ_><<<grid1, 256, 0, st>>>(g)
 #define RF_G2_TJ(NA_) do { if (tj == 2) RF_G2(NA_, 2); else RF_G2(NA_, 4); } while (0)
-    if (ntap == 9) gram2_kernel<9, 1, 1><<<dim3((unsigned)nslab, (unsigned)cdiv(Ca, 16), (unsigned)cdiv(Cb, 16)), 256, 0, st>>>(g);
+    if (ntap == 9 && na == 2) gram2_kernel<9, 2, 1><<<dim3((unsigned)nslab, (unsigned)cdiv(Ca, 32), (unsigned)cdiv(Cb, 16)), 256, 0, st>>>(g);
+    else if (ntap == 9) gram2_kernel<9, 1, 1><<<dim3((unsigned)nslab, (unsigned)cdiv(Ca, 16), (unsigned)cdiv(Cb, 16)), 256, 0, st>>>(g);
     else if (na == 6) RF_G2_TJ(6);
     else if (na == 4) RF_G2_TJ(4);
     else if (na == 3) RF_G2_TJ(3);

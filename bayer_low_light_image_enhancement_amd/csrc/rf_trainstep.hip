@@ -19,7 +19,9 @@
 //     i.e. d[q;k] = M2 [q;k] with a per-image 2C x 2C matrix and dv = blockdiag(A^T) do: two 1x1 GEMMs with per-image weights.
 // Variants 'plain' (conv branch) and 'flca' (rf_train.hip: launch_flca_backward).
 #include <cstring>
+#include <map>
 #include <string>
+#include <utility>
 #include <vector>
 #include "rf_handle.h"
 
@@ -56,7 +58,8 @@ struct TrainPlan {
     float *gscratch, *guide[4], *flca_scr;
     float *tA, *tB, *tC, *tD, *tE;     // backward temporaries (3 * U0 each)
     float *dskip[3], *dpred, *ga, *gb;
-    float *wt1, *wt2;                  // on-the-fly packed / flipped weights
+    float *wt1, *wt2;                  // on-the-fly packed / flipped weights (shapes the pack cache does not hold)
+    float *pack_cache;                 // every packed weight form of the step, written by a few batched launches at its start
     float *part;                       // reduction partials
     float *small;                      // attention: per-image C x C matrices and packed per-image weights
     float *loss_part;
@@ -64,6 +67,41 @@ struct TrainPlan {
 };
 
 size_t max_sz(size_t a, size_t b) { return a > b ? a : b; }
+
+// ---- pack cache ------------------------------------------------------------------------------------------------------
+// The step needs most weights in two packed forms: as they multiply in the forward (PF_N) and transposed -- 3x3: also tap-flipped
+// -- for the dX product of the backward (PF_T); ConvTranspose2d has a third (PF_CTB, its dX GEMM).  They were packed where they
+// were used: ~125 launches of a few microseconds per step.  Now the list is derived from the parameter shapes and filled by
+// launch_pack_batch (3 launches) before the forward; the helpers look a weight up by (pointer, form).
+enum PackForm { PF_N = 0, PF_T = 1, PF_CTB = 2 };
+typedef std::map<std::pair<const float*, int>, const float*> PackMap;
+
+size_t build_pack_list(const rf_handle* h, float* base, std::vector<PackDesc>* list, PackMap* map) {
+    size_t off = 0;
+    auto add = [&](const Param& q, int form, int kind, int rows, int cols, int64_t rs, int64_t cs, int flip) {
+        PackDesc d{q.ptr, base ? base + off : nullptr, kind, rows, cols, rs, cs, flip};
+        if (list) list->push_back(d);
+        if (map) (*map)[std::make_pair(q.ptr, form)] = d.dst;
+        off += align_up(pack_desc_floats(d), 64);
+    };
+    for (const Param& q : h->params) {
+        if (q.ndim != 4 || q.name.find("FLCA.") != std::string::npos) continue;      // the gate convolutions have their own kernels
+        const int n0 = (int)q.shape[0], n1 = (int)q.shape[1], kh = (int)q.shape[2];
+        if (kh == 1) {                                   // 1x1 conv [Cout][K]
+            add(q, PF_N, 0, n0, n1, n1, 1, 0);
+            add(q, PF_T, 0, n1, n0, 1, n1, 0);
+        } else if (kh == 3 && n1 == 1) {                 // depthwise [C][1][3][3]: dX runs the forward kernel on flipped taps
+            add(q, PF_T, 2, n0, 9, 9, 1, 0);
+        } else if (kh == 3) {                            // 3x3 conv [Cout][Cin][3][3]
+            add(q, PF_N, 1, n0, n1, (int64_t)n1 * 9, 9, 0);
+            add(q, PF_T, 1, n1, n0, 9, (int64_t)n1 * 9, 1);
+        } else if (kh == 2) {                            // ConvTranspose2d [Cin][Cout][2][2]: GEMM row 4 o + 2 i + j, column k (pack_convT)
+            add(q, PF_N, 0, 4 * n1, n0, 1, (int64_t)4 * n1, 0);
+            add(q, PF_CTB, 0, n0, 4 * n1, (int64_t)4 * n1, 1, 0);
+        }
+    }
+    return off;
+}
 
 int make_train_plan(const rf_handle* h, float* base, int B, int H, int W, TrainPlan& p) {
     const rf_config& c = h->cfg;
@@ -119,6 +157,7 @@ int make_train_plan(const rf_handle* h, float* base, int B, int H, int W, TrainP
     p.tA = b.take(T); p.tB = b.take(T); p.tC = b.take(T); p.tD = b.take(T); p.tE = b.take(64);
     p.ga = b.take(U0); p.gb = b.take(U0);
     p.wt1 = b.take(wt); p.wt2 = b.take(wt);
+    p.pack_cache = b.take(build_pack_list(h, nullptr, nullptr, nullptr));
     p.part = b.take(max_sz(part, (size_t)B * 64 * 512));
     p.small = b.take(small);
     p.loss_part = b.take(4096);
@@ -135,13 +174,20 @@ struct Ctx {
     float* grads;      // flat gradient buffer
     int B;
     hipStream_t st;
+    const PackMap* packs = nullptr;
     float* G(const std::string& n) const { return grads + h->flat_offset[rf_param_index(h, n)]; }
+    const float* pk(const float* w, int form) const {      // nullptr: not in the cache (the helper packs on the fly)
+        if (!packs) return nullptr;
+        auto it = packs->find(std::make_pair(w, form));
+        return it == packs->end() ? nullptr : it->second;
+    }
 };
 
 // ---- forward helpers (raw weights, packed on the fly) ---------------------------------------------------------------
 int f_conv1x1(const Ctx& c, const float* x1, int C1, const float* x2, int C2, const float* w, const float* bias, const float* ln_w, const float* ln_b,
               const float* res, float* out, int Cout, int P_, const float* wp_pre = nullptr, int64_t wp_bstride = 0) {
     const int K = C1 + C2;
+    if (!wp_pre) wp_pre = c.pk(w, PF_N);
     if (!wp_pre) RF_TRY(pack_1x1(w, c.p->wt1, Cout, K, K, 1, c.st));
     Conv1x1Args a{};
     a.x1 = x1; a.C1 = C1; a.x1_bstride = (int64_t)C1 * P_;
@@ -154,6 +200,7 @@ int f_conv1x1(const Ctx& c, const float* x1, int C1, const float* x2, int C2, co
 
 int f_conv3x3(const Ctx& c, const float* x, int Cin, const float* w, const float* bias, float* out, int Cout, int hh, int ww, int act, int store,
               int unshuffle_in = 0, const float* wp_pre = nullptr) {
+    if (!wp_pre && w) wp_pre = c.pk(w, PF_N);
     if (!wp_pre) RF_TRY(pack_3x3(w, c.p->wt1, Cout, Cin, c.st));
     Conv3x3Args a{};
     a.x = x; a.x_bstride = (int64_t)Cin * hh * ww; a.wp = wp_pre ? wp_pre : c.p->wt1; a.bias = bias; a.out = out;
@@ -173,9 +220,13 @@ int f_dw(const Ctx& c, const float* x, const float* w, const float* bias, float*
 // dX of a 1x1 conv with raw weight [Cout][K]: conv1x1 with W^T (out: K channels)
 // (dy_bstride: floats between the images of dy when it is a channel slice of a wider tensor; 0 = contiguous)
 int b_conv1x1_dx(const Ctx& c, const float* dy, int Cout, const float* w, int K, float* dx, int P_, const float* res = nullptr, int64_t dy_bstride = 0) {
-    RF_TRY(pack_1x1(w, c.p->wt1, K, Cout, 1, K, c.st));                 // rows = k, cols = co : element W[co][k] at co * K + k
+    const float* wt = c.pk(w, PF_T);
+    if (!wt) {
+        RF_TRY(pack_1x1(w, c.p->wt1, K, Cout, 1, K, c.st));             // rows = k, cols = co : element W[co][k] at co * K + k
+        wt = c.p->wt1;
+    }
     Conv1x1Args a{};
-    a.x1 = dy; a.C1 = Cout; a.x1_bstride = dy_bstride ? dy_bstride : (int64_t)Cout * P_; a.wp = c.p->wt1;
+    a.x1 = dy; a.C1 = Cout; a.x1_bstride = dy_bstride ? dy_bstride : (int64_t)Cout * P_; a.wp = wt;
     a.res = res; a.res_bstride = (int64_t)K * P_;
     a.out = dx; a.out_bstride = (int64_t)K * P_; a.Cout = K; a.B = c.B; a.P = P_; a.w = P_;
     return launch_conv1x1(a, c.st);
@@ -189,9 +240,13 @@ int b_conv1x1_dw(const Ctx& c, const float* dy, int Cout, const float* x, int Cx
 }
 
 int b_conv3x3_dx(const Ctx& c, const float* dy, int Cout, const float* w, int Cin, float* dx, int hh, int ww) {
-    RF_TRY(launch_flip3x3(w, c.p->wt2, Cout, Cin, 1, c.st));            // [Cin][Cout][flipped taps]
-    RF_TRY(pack_3x3(c.p->wt2, c.p->wt1, Cin, Cout, c.st));
-    return f_conv3x3(c, dy, Cout, nullptr, nullptr, dx, Cin, hh, ww, 0, 0, 0, c.p->wt1);
+    const float* wt = c.pk(w, PF_T);
+    if (!wt) {
+        RF_TRY(launch_flip3x3(w, c.p->wt2, Cout, Cin, 1, c.st));        // [Cin][Cout][flipped taps]
+        RF_TRY(pack_3x3(c.p->wt2, c.p->wt1, Cin, Cout, c.st));
+        wt = c.p->wt1;
+    }
+    return f_conv3x3(c, dy, Cout, nullptr, nullptr, dx, Cin, hh, ww, 0, 0, 0, wt);
 }
 
 int b_conv3x3_dw(const Ctx& c, const float* dy, int Cout, const float* x, int Cin, float* dW, float* db, int hh, int ww) {
@@ -200,8 +255,12 @@ int b_conv3x3_dw(const Ctx& c, const float* dy, int Cout, const float* x, int Ci
 
 int b_dw(const Ctx& c, const float* dy, const float* x, const float* w, float* dx, float* dW, float* db, int C, int hh, int ww) {
     RF_TRY(launch_dw_wgrad(x, dy, dW, db, c.p->part, c.B, C, hh, ww, 1, c.st));
-    RF_TRY(launch_flip3x3(w, c.p->wt2, C, 1, 0, c.st));
-    return f_dw(c, dy, c.p->wt2, nullptr, dx, C, hh, ww);
+    const float* wf = c.pk(w, PF_T);
+    if (!wf) {
+        RF_TRY(launch_flip3x3(w, c.p->wt2, C, 1, 0, c.st));
+        wf = c.p->wt2;
+    }
+    return f_dw(c, dy, wf, nullptr, dx, C, hh, ww);
 }
 
 // ---- attention, small per-(head, image) kernel ----------------------------------------------------------------------
@@ -577,6 +636,11 @@ int rf_train_step(rf_handle* h, const float* in, const float* gt, float* grads, 
     const int d = cfg.dim, oc = cfg.out_channels;
     Ctx c{h, &p, grads, B, st};
     RF_TRY(check_hip(hipMemsetAsync(grads, 0, h->flat_floats * sizeof(float), st), "memset grads"));
+    std::vector<PackDesc> pack_list;
+    PackMap pack_map;
+    build_pack_list(h, p.pack_cache, &pack_list, &pack_map);
+    RF_TRY(launch_pack_batch(pack_list.data(), (int)pack_list.size(), st));
+    c.packs = &pack_map;
 
     // ------------------------------------------------------------------ forward
     RF_TRY(launch_pixel_unshuffle2(in, p.x4, B, 1, H, W, st));
@@ -597,9 +661,13 @@ int rf_train_step(rf_handle* h, const float* in, const float* gt, float* grads, 
     for (int i = 1; i <= 3; ++i) {
         const int lvl = 3 - i, C = d << lvl, hh = H >> lvl, ww = W >> lvl, Pn = hh * ww;
         const std::string u = "up" + std::to_string(i), r = "channel_reduce" + std::to_string(i);
-        RF_TRY(pack_convT(P(h, u + ".weight"), p.wt1, 2 * C, C, st));
+        const float* upw = c.pk(P(h, u + ".weight"), PF_N);
+        if (!upw) {
+            RF_TRY(pack_convT(P(h, u + ".weight"), p.wt1, 2 * C, C, st));
+            upw = p.wt1;
+        }
         Conv1x1Args up{};
-        up.x1 = cur; up.C1 = 2 * C; up.x1_bstride = (int64_t)2 * C * (Pn / 4); up.wp = p.wt1; up.bias = P(h, u + ".bias");
+        up.x1 = cur; up.C1 = 2 * C; up.x1_bstride = (int64_t)2 * C * (Pn / 4); up.wp = upw; up.bias = P(h, u + ".bias");
         up.out = p.up[i - 1]; up.out_bstride = (int64_t)C * Pn; up.Cout = 4 * C; up.B = B; up.P = Pn / 4; up.w = ww / 2; up.mode = 1;
         RF_TRY(launch_conv1x1(up, st));
         RF_TRY(f_conv1x1(c, p.up[i - 1], C, p.st[lvl + 1].out, C, P(h, r + ".weight"), P(h, r + ".bias"), nullptr, nullptr, nullptr, p.catr[i - 1], C, Pn));
@@ -645,9 +713,13 @@ int rf_train_step(rf_handle* h, const float* in, const float* gt, float* grads, 
         const float* xin = (i == 1) ? p.st[4].out : p.st[4 + i - 1].out;
         RF_TRY(launch_gram2(xin, (int64_t)2 * C * (Pn / 4), 2 * C, p.tB, (int64_t)4 * C * (Pn / 4), 4 * C, c.G(u + ".weight"), 4 * C, p.part, B, hh / 2, ww / 2,
                             1, 0, 0, 0, 0, 1, st));
-        RF_TRY(pack_1x1(P(h, u + ".weight"), p.wt1, 2 * C, 4 * C, 4 * C, 1, st));
+        const float* upb = c.pk(P(h, u + ".weight"), PF_CTB);
+        if (!upb) {
+            RF_TRY(pack_1x1(P(h, u + ".weight"), p.wt1, 2 * C, 4 * C, 4 * C, 1, st));
+            upb = p.wt1;
+        }
         Conv1x1Args a{};
-        a.x1 = p.tB; a.C1 = 4 * C; a.x1_bstride = (int64_t)4 * C * (Pn / 4); a.wp = p.wt1;
+        a.x1 = p.tB; a.C1 = 4 * C; a.x1_bstride = (int64_t)4 * C * (Pn / 4); a.wp = upb;
         a.out = ga; a.out_bstride = (int64_t)2 * C * (Pn / 4); a.Cout = 2 * C; a.B = B; a.P = Pn / 4; a.w = ww / 2;
         RF_TRY(launch_conv1x1(a, st));                                                         // ga = d(previous stage out) [B, 2C, Pn/4]
         note.done(u + ".");                                                                    // up_i and channel_reduce_i
