@@ -146,7 +146,7 @@ int pack_convT(const float* w, float* packed, int Cin, int Cout, hipStream_t st)
 // ---- batched weight packing (rf_pack.hip; the training step packs every weight form it needs in a few launches)
 struct PackDesc {
     const float* src; float* dst;
-    int kind;              // 0: 1x1 generic strides, 1: 3x3 Winograd generic strides (+ tap flip), 2: depthwise taps flipped
+    int kind;              // 0: 1x1 generic strides, 1: 3x3 Winograd generic strides (+ tap flip), 2: depthwise taps flipped, 3: 1x1 in b3 form
     int rows, cols;        // of the packed matrix (rows = its output channels)
     int64_t rs, cs;        // floats between rows / columns of src
     int flip;
@@ -310,7 +310,8 @@ int launch_tc_color_head(float* x, const float* const* prm, int B, size_t P, hip
 size_t gram2_partial_floats(int B, int Ca, int Cb, int h, int w, int ntap);
 int launch_gram2(const float* a, int64_t a_bstride, int Ca, const float* b, int64_t b_bstride, int Cb, float* out, int ld, float* partial,
                  int B, int h, int w, int ntap, int sy, int sx, int per_image, size_t out_istride, int accumulate, hipStream_t st,
-                 float* db = nullptr /* [Ca] (+)= row sums of a over all images and pixels: the bias gradient of the same layer */);
+                 float* db = nullptr /* [Ca] (+)= row sums of a over all images and pixels: the bias gradient of the same layer */,
+                 const float* b2 = nullptr, int64_t b2_bstride = 0, int Cb2 = 0 /* input = cat(b, b2) along channels, read in place */);
 int launch_reduce_rows(const float* partial, float* out, int nrows, size_t n, int accumulate, hipStream_t st);
 int chan_sum_nblk(int P);
 int launch_chan_sum(const float* x, int64_t bstride, float* out, float* partial, int B, int C, int P, int accumulate, hipStream_t st);

@@ -78,9 +78,11 @@ __global__ void __launch_bounds__(256) pack_3x3_kernel(const float* __restrict__
 // kind 1: 3x3 Winograd, element (row, col, tap) = src[row * rs + col * cs + (flip ? 8 - tap : tap)]   (pack_3x3 layout;
 //         the dX weights of a 3x3 conv = rows and columns exchanged, taps flipped)
 // kind 2: depthwise taps flipped, dst[c * 9 + 8 - t] = src[c * 9 + t]
+// kind 3: kind 0's matrix in b3 form (pack_1x1_b3 layout)
 __device__ __forceinline__ size_t pack_item_total(const PackDesc& d) {
     if (d.kind == 0) return (size_t)((d.rows + 15) >> 4) * ((d.cols + 3) >> 2) * 64;
     if (d.kind == 1) return (size_t)(((d.cols + 7) >> 3) * 2) * 18 * ((d.rows + 15) >> 4) * 64;
+    if (d.kind == 3) return (size_t)((d.rows + 15) >> 4) * ((d.cols + 31) >> 5) * 512;      // (row, col) pairs of the padded matrix
     return (size_t)d.rows * 9;
 }
 
@@ -110,6 +112,10 @@ __global__ void __launch_bounds__(256) pack_batch_kernel(PackBatch batch) {
                   : j == 3 ? fmaf(g1, 1.0f / 12.0f, e02) : j == 4 ? fmaf(g1, -1.0f / 12.0f, e02) : g2;
             }
             packed[idx] = u;
+        } else if (d.kind == 3) {
+            const int NT = (d.rows + 15) >> 4, NB = (d.cols + 31) >> 5;
+            const int k = (int)(idx % ((size_t)NB * 32)), co = (int)(idx / ((size_t)NB * 32));
+            b3_store(reinterpret_cast<unsigned short*>(packed), NT, co, k, (co < d.rows && k < d.cols) ? w[co * d.rs + k * d.cs] : 0.f);
         } else {
             const int t = (int)(idx % 9);
             packed[idx - t + 8 - t] = w[idx];
@@ -120,6 +126,7 @@ __global__ void __launch_bounds__(256) pack_batch_kernel(PackBatch batch) {
 size_t pack_desc_floats(const PackDesc& d) {
     if (d.kind == 0) return packed1x1_floats(d.cols, d.rows);
     if (d.kind == 1) return packed3x3_floats(d.cols, d.rows);
+    if (d.kind == 3) return packed1x1_b3_floats(d.cols, d.rows);
     return (size_t)d.rows * 9;
 }
 

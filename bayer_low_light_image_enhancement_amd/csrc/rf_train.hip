@@ -29,7 +29,8 @@ __device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast
 // ---------------------------------------------------------------------------------------------
 struct Gram2Args {
     const float* a; int64_t a_bstride; int Ca;     // dOut  [B][Ca][h][w]
-    const float* b; int64_t b_bstride; int Cb;     // input [B][Cb][h][w]
+    const float* b; int64_t b_bstride; int Cb;     // input [B][Cb][h][w]; rows >= Cb1 come from b2 (a concatenated input read in place)
+    const float* b2; int64_t b2_bstride; int Cb1;
     float* partial;
     int B, h, w, sy, sx, slab_px, slabs_per_image;
     float* bias_partial;                           // [slab][Ca] row sums of A (the bias gradient of the same layer) or nullptr
@@ -58,8 +59,8 @@ __global__ void __launch_bounds__(256) gram2_kernel(Gram2Args g) {
     const float* brow[TJ];
 #pragma unroll
     for (int t = 0; t < TJ; ++t) {
-        const int jb = 16 * (tjg * TJ + t) + r;
-        brow[t] = g.b + (size_t)img * g.b_bstride + (size_t)(jb < g.Cb ? jb : g.Cb - 1) * P;
+        const int jb = 16 * (tjg * TJ + t) + r, jc = jb < g.Cb ? jb : g.Cb - 1;
+        brow[t] = jc < g.Cb1 ? g.b + (size_t)img * g.b_bstride + (size_t)jc * P : g.b2 + (size_t)img * g.b2_bstride + (size_t)(jc - g.Cb1) * P;
     }
     f32x4 acc[NTAP * NA][TJ];       // [tap * NA + A tile]
 #pragma unroll
@@ -650,13 +651,17 @@ size_t gram2_partial_floats(int B, int Ca, int Cb, int h, int w, int ntap) {
 // out[(i * ld + j) * ntap + tap] = weight layout [Ca][ld >= Cb][taps] (ntap = 9: the 3x3 window in (dy, dx) row-major order;
 // ntap = 1: the single shift (sy, sx)); per_image: out[b * out_istride + ...] without the sum over images; accumulate adds
 int launch_gram2(const float* a, int64_t a_bstride, int Ca, const float* b, int64_t b_bstride, int Cb, float* out, int ld, float* partial,
-                 int B, int h, int w, int ntap, int sy, int sx, int per_image, size_t out_istride, int accumulate, hipStream_t st, float* db) {
+                 int B, int h, int w, int ntap, int sy, int sx, int per_image, size_t out_istride, int accumulate, hipStream_t st, float* db,
+                 const float* b2, int64_t b2_bstride, int Cb2) {
     RF_CHECK_ARG(w % 4 == 0 && aligned16(a) && aligned16(b) && a_bstride % 4 == 0 && b_bstride % 4 == 0,
                  "gram2: width %d must be a multiple of 4 and the operands 16-byte aligned", w);
     RF_CHECK_ARG(ntap == 1 || ntap == 9, "gram2: ntap must be 1 or 9");
     RF_CHECK_ARG(ntap == 9 || sx == 0, "gram2: the single-tap form shifts rows only (sx = %d)", sx);
     RF_CHECK_ARG(!db || !per_image, "gram2: the bias gradient is a sum over all images");
-    Gram2Args g{a, a_bstride, Ca, b, b_bstride, Cb, partial, B, h, w, sy, sx, 0, 0, nullptr};
+    RF_CHECK_ARG(Cb2 == 0 || (b2 && aligned16(b2) && b2_bstride % 4 == 0), "gram2: bad second input");
+    const int Cb1 = Cb;
+    Cb += Cb2;                                      // rows [Cb1, Cb1 + Cb2) of the input are b2's channels
+    Gram2Args g{a, a_bstride, Ca, b, b_bstride, Cb, Cb2 ? b2 : b, Cb2 ? b2_bstride : b_bstride, Cb1, partial, B, h, w, sy, sx, 0, 0, nullptr};
     const int na = gram2_na(Ca, ntap), tj = gram2_tj(Cb, ntap);
     gram2_slabs(B, h * w, cdiv(Ca, 16 * na) * cdiv(Cb, 16 * tj), &g.slab_px, &g.slabs_per_image);
     const int nslab = B * g.slabs_per_image;

@@ -73,7 +73,7 @@ size_t max_sz(size_t a, size_t b) { return a > b ? a : b; }
 // -- for the dX product of the backward (PF_T); ConvTranspose2d has a third (PF_CTB, its dX GEMM).  They were packed where they
 // were used: ~125 launches of a few microseconds per step.  Now the list is derived from the parameter shapes and filled by
 // launch_pack_batch (3 launches) before the forward; the helpers look a weight up by (pointer, form).
-enum PackForm { PF_N = 0, PF_T = 1, PF_CTB = 2 };
+enum PackForm { PF_N = 0, PF_T = 1, PF_CTB = 2, PF_N3 = 3, PF_T3 = 4, PF_CTB3 = 5 };      // ..3: the same matrix in b3 form (K >= 128: bf16x3 GEMM)
 typedef std::map<std::pair<const float*, int>, const float*> PackMap;
 
 size_t build_pack_list(const rf_handle* h, float* base, std::vector<PackDesc>* list, PackMap* map) {
@@ -90,6 +90,8 @@ size_t build_pack_list(const rf_handle* h, float* base, std::vector<PackDesc>* l
         if (kh == 1) {                                   // 1x1 conv [Cout][K]
             add(q, PF_N, 0, n0, n1, n1, 1, 0);
             add(q, PF_T, 0, n1, n0, 1, n1, 0);
+            if (n1 >= 128) add(q, PF_N3, 3, n0, n1, n1, 1, 0);
+            if (n0 >= 128) add(q, PF_T3, 3, n1, n0, 1, n1, 0);
         } else if (kh == 3 && n1 == 1) {                 // depthwise [C][1][3][3]: dX runs the forward kernel on flipped taps
             add(q, PF_T, 2, n0, 9, 9, 1, 0);
         } else if (kh == 3) {                            // 3x3 conv [Cout][Cin][3][3]
@@ -98,6 +100,8 @@ size_t build_pack_list(const rf_handle* h, float* base, std::vector<PackDesc>* l
         } else if (kh == 2) {                            // ConvTranspose2d [Cin][Cout][2][2]: GEMM row 4 o + 2 i + j, column k (pack_convT)
             add(q, PF_N, 0, 4 * n1, n0, 1, (int64_t)4 * n1, 0);
             add(q, PF_CTB, 0, n0, 4 * n1, (int64_t)4 * n1, 1, 0);
+            if (n0 >= 128) add(q, PF_N3, 3, 4 * n1, n0, 1, (int64_t)4 * n1, 0);
+            if (4 * n1 >= 128) add(q, PF_CTB3, 3, n0, 4 * n1, (int64_t)4 * n1, 1, 0);
         }
     }
     return off;
@@ -187,9 +191,14 @@ struct Ctx {
 int f_conv1x1(const Ctx& c, const float* x1, int C1, const float* x2, int C2, const float* w, const float* bias, const float* ln_w, const float* ln_b,
               const float* res, float* out, int Cout, int P_, const float* wp_pre = nullptr, int64_t wp_bstride = 0) {
     const int K = C1 + C2;
-    if (!wp_pre) wp_pre = c.pk(w, PF_N);
+    const float* wp3 = nullptr;
+    if (!wp_pre) {
+        wp_pre = c.pk(w, PF_N);
+        if (wp_pre) wp3 = c.pk(w, PF_N3);
+    }
     if (!wp_pre) RF_TRY(pack_1x1(w, c.p->wt1, Cout, K, K, 1, c.st));
     Conv1x1Args a{};
+    a.wp3 = wp3;
     a.x1 = x1; a.C1 = C1; a.x1_bstride = (int64_t)C1 * P_;
     a.x2 = x2; a.C2 = C2; a.x2_bstride = (int64_t)C2 * P_;
     a.wp = wp_pre ? wp_pre : c.p->wt1; a.wp_bstride = wp_bstride; a.bias = bias; a.ln_w = ln_w; a.ln_b = ln_b; a.ln_eps = 1e-5f;
@@ -227,16 +236,18 @@ int b_conv1x1_dx(const Ctx& c, const float* dy, int Cout, const float* w, int K,
     }
     Conv1x1Args a{};
     a.x1 = dy; a.C1 = Cout; a.x1_bstride = dy_bstride ? dy_bstride : (int64_t)Cout * P_; a.wp = wt;
+    if (wt != c.p->wt1) a.wp3 = c.pk(w, PF_T3);
     a.res = res; a.res_bstride = (int64_t)K * P_;
     a.out = dx; a.out_bstride = (int64_t)K * P_; a.Cout = K; a.B = c.B; a.P = P_; a.w = P_;
     return launch_conv1x1(a, c.st);
 }
 
 // dW [Cout][ld] columns [col0, col0 + Cx) += / = gram2(dy, x);  db = channel sums of dy, taken in the same pass
+// (x2 / Cx2: the layer's input is cat(x, x2) along channels, read in place)
 int b_conv1x1_dw(const Ctx& c, const float* dy, int Cout, const float* x, int Cx, float* dW, int ld, int col0, float* db, int hh, int ww,
-                 int64_t dy_bstride = 0) {
+                 int64_t dy_bstride = 0, const float* x2 = nullptr, int Cx2 = 0) {
     return launch_gram2(dy, dy_bstride ? dy_bstride : (int64_t)Cout * hh * ww, Cout, x, (int64_t)Cx * hh * ww, Cx, dW + col0, ld, c.p->part, c.B, hh, ww,
-                        1, 0, 0, 0, 0, 1, c.st, col0 == 0 ? db : nullptr);
+                        1, 0, 0, 0, 0, 1, c.st, col0 == 0 ? db : nullptr, x2, (int64_t)Cx2 * hh * ww, Cx2);
 }
 
 int b_conv3x3_dx(const Ctx& c, const float* dy, int Cout, const float* w, int Cin, float* dx, int hh, int ww) {
@@ -467,8 +478,7 @@ int stage_backward(const Ctx& c, int i, int lvl, float* dout, float* din, int H,
     RF_TRY(b_conv3x3_dw(c, tA, C, s.cr, C, c.G(pre + "Conv_out.weight"), c.G(pre + "Conv_out.bias"), hh, ww));
     RF_TRY(b_conv3x3_dx(c, tA, C, P(h, pre + "Conv_out.weight"), C, tB, hh, ww));                     // tB = dcr
     // channel_reduce over cat[xs, trans]
-    RF_TRY(b_conv1x1_dw(c, tB, C, s.xs, C, c.G(pre + "channel_reduce.weight"), 2 * C, 0, c.G(pre + "channel_reduce.bias"), hh, ww));
-    RF_TRY(b_conv1x1_dw(c, tB, C, s.trans, C, c.G(pre + "channel_reduce.weight"), 2 * C, C, nullptr, hh, ww));
+    RF_TRY(b_conv1x1_dw(c, tB, C, s.xs, C, c.G(pre + "channel_reduce.weight"), 2 * C, 0, c.G(pre + "channel_reduce.bias"), hh, ww, 0, s.trans, C));
     RF_TRY(b_conv1x1_dx(c, tB, C, P(h, pre + "channel_reduce.weight"), 2 * C, tC, Pn));               // tC = [dxs ; dtrans] per image
     // dxs and dtrans are read in place as channel slices of tC (image stride 2C Pn) by the kernels that take a stride; only the
     // plain variant's element-wise LeakyReLU adjoint needs contiguous halves (tA = dxs, tD = dtrans)
@@ -668,6 +678,7 @@ int rf_train_step(rf_handle* h, const float* in, const float* gt, float* grads, 
         }
         Conv1x1Args up{};
         up.x1 = cur; up.C1 = 2 * C; up.x1_bstride = (int64_t)2 * C * (Pn / 4); up.wp = upw; up.bias = P(h, u + ".bias");
+        if (upw != p.wt1) up.wp3 = c.pk(P(h, u + ".weight"), PF_N3);
         up.out = p.up[i - 1]; up.out_bstride = (int64_t)C * Pn; up.Cout = 4 * C; up.B = B; up.P = Pn / 4; up.w = ww / 2; up.mode = 1;
         RF_TRY(launch_conv1x1(up, st));
         RF_TRY(f_conv1x1(c, p.up[i - 1], C, p.st[lvl + 1].out, C, P(h, r + ".weight"), P(h, r + ".bias"), nullptr, nullptr, nullptr, p.catr[i - 1], C, Pn));
@@ -703,8 +714,7 @@ int rf_train_step(rf_handle* h, const float* in, const float* gt, float* grads, 
         RF_TRY(stage_backward(c, 4 + i, lvl, ga, gb, H, W));                                   // gb = d(catr_i)
         note.done("conv_tran" + std::to_string(4 + i) + ".");
         // channel_reduce_i over cat[up, skip]
-        RF_TRY(b_conv1x1_dw(c, gb, C, p.up[i - 1], C, c.G(r + ".weight"), 2 * C, 0, c.G(r + ".bias"), hh, ww));
-        RF_TRY(b_conv1x1_dw(c, gb, C, p.st[lvl + 1].out, C, c.G(r + ".weight"), 2 * C, C, nullptr, hh, ww));
+        RF_TRY(b_conv1x1_dw(c, gb, C, p.up[i - 1], C, c.G(r + ".weight"), 2 * C, 0, c.G(r + ".bias"), hh, ww, 0, p.st[lvl + 1].out, C));
         RF_TRY(b_conv1x1_dx(c, gb, C, P(h, r + ".weight"), 2 * C, p.tC, Pn));                 // tC = [dup ; dskip]
         RF_TRY(launch_split_halves(p.tC, p.tA, p.dskip[lvl], B, C, Pn, st));
         // ConvTranspose2d(2C -> C): dX = conv1x1(unshuffle(dup), W as [2C][4C]);  dW = gram2(x, unshuffle(dup));  db = channel sums of dup
@@ -720,6 +730,7 @@ int rf_train_step(rf_handle* h, const float* in, const float* gt, float* grads, 
         }
         Conv1x1Args a{};
         a.x1 = p.tB; a.C1 = 4 * C; a.x1_bstride = (int64_t)4 * C * (Pn / 4); a.wp = upb;
+        if (upb != p.wt1) a.wp3 = c.pk(P(h, u + ".weight"), PF_CTB3);
         a.out = ga; a.out_bstride = (int64_t)2 * C * (Pn / 4); a.Cout = 2 * C; a.B = B; a.P = Pn / 4; a.w = ww / 2;
         RF_TRY(launch_conv1x1(a, st));                                                         // ga = d(previous stage out) [B, 2C, Pn/4]
         note.done(u + ".");                                                                    // up_i and channel_reduce_i
