@@ -34,19 +34,38 @@ struct Gram2Args {
     float* partial;
     int B, h, w, sy, sx, slab_px, slabs_per_image;
     float* bias_partial;                           // [slab][Ca] row sums of A (the bias gradient of the same layer) or nullptr
+    int nslab, nty, ntz;                           // grid decomposition (gram2_block)
 };
+
+// Workgroup -> (slab, A tile group ti, B tile group tjg).  The nty * ntz tile workgroups of one slab read the same pixels of A
+// and B; the hardware deals consecutive workgroup ids round-robin over the 8 XCDs (one L2 each), so the ids are arranged for the
+// tiles of a slab to follow each other ON ONE XCD: its L2 serves the re-reads (with slab as the fast grid index the tiles of a
+// slab ran far apart in time and every one of them came from HBM: 2.5 x the algorithmic bytes at levels 1-3).
+__device__ __forceinline__ bool gram2_block(const Gram2Args& g, int* slab, int* ti, int* tjg) {
+    const int T = g.nty * g.ntz, bid = blockIdx.x;
+    const int tile = (bid >> 3) % T;
+    *slab = (bid & 7) + 8 * (bid / (8 * T));
+    *ti = tile % g.nty;
+    *tjg = tile / g.nty;
+    return *slab < g.nslab;
+}
 
 // NA (single-tap form only): A tiles per workgroup.  With one A tile the B rows were re-read once per 16 output rows (Ca = 96:
 // 2.25 x the algorithmic bytes, 0.22 of HBM); NA = Ca / 16 (up to 6) reads both operands once.
 // TJ: B tiles per workgroup (single-tap form: 4, or 2 when Cb <= 32 -- with four, half the loads and MFMAs of every level-0
 // layer were spent on clamped duplicate rows).  The row sums of A -- the bias gradient of the layer whose weight gradient this
 // is -- are accumulated per lane on the way (4 NA additions beside 16 NA TJ MFMAs) instead of by a second pass over dOut.
-template <int NTAP, int NA, int TJ>
+// MASK (single-tap form): a wave's 16-pixel step may straddle the end of the image (P % 16 != 0); the 3x3 form always masks.
+template <int NTAP, int NA, int TJ, bool MASK = true>
 __global__ void __launch_bounds__(256) gram2_kernel(Gram2Args g) {
     static_assert(NTAP == 1 || TJ == 1, "several B tiles only in the single-tap form");
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    // the wave index as a SCALAR: the step loop and everything that guards a load is then a scalar branch.  With `wave` in a
+    // vector register hipcc treated the (wave-uniform) loop control as divergent, wrapped every prefetch in an EXEC-masked block
+    // and closed it with s_waitcnt vmcnt(2..3): the loads of the NEXT step were waited for as soon as they were issued.
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int r = lane & 15, kq = lane >> 4;
-    const int slab = blockIdx.x, ti = blockIdx.y, tjg = blockIdx.z;
+    int slab, ti, tjg;
+    if (!gram2_block(g, &slab, &ti, &tjg)) return;          // padding of the slab count to a multiple of 8 (whole workgroups)
     const int img = slab / g.slabs_per_image, sl = slab - img * g.slabs_per_image;
     const int h = g.h, w = g.w, P = h * w;
     const int n_lo = sl * g.slab_px, n_hi = (n_lo + g.slab_px < P) ? n_lo + g.slab_px : P;
@@ -61,6 +80,32 @@ __global__ void __launch_bounds__(256) gram2_kernel(Gram2Args g) {
     for (int t = 0; t < TJ; ++t) {
         const int jb = 16 * (tjg * TJ + t) + r, jc = jb < g.Cb ? jb : g.Cb - 1;
         brow[t] = jc < g.Cb1 ? g.b + (size_t)img * g.b_bstride + (size_t)jc * P : g.b2 + (size_t)img * g.b2_bstride + (size_t)(jc - g.Cb1) * P;
+    }
+    // single-tap form: wave-uniform tile bases + 32-bit lane offsets (the loads take the scalar-base addressing mode: one VALU
+    // addition per load instead of a 64-bit pointer sum), no row / column arithmetic (the shift is zero: launch_gram2 checks), and
+    // no masks when every 16-pixel step of a wave is entirely inside the image (P % 16 == 0).  The VALU instructions of a step are
+    // what limited this kernel: f32 MFMA time and VALU time add up, and there were four of them for every MFMA.
+    const float* abase[NA];
+    unsigned aoff[NA];
+    const float* bbase[TJ];
+    unsigned boff[TJ];
+    if constexpr (NTAP == 1) {
+        const int nta = (g.Ca + 15) >> 4, ntb = (g.Cb + 15) >> 4;
+#pragma unroll
+        for (int u = 0; u < NA; ++u) {
+            const int tile = (ti * NA + u < nta) ? ti * NA + u : nta - 1;         // uniform; a clamped duplicate tile is never stored
+            const int rr = (16 * tile + r < g.Ca) ? r : g.Ca - 1 - 16 * tile;
+            abase[u] = g.a + (size_t)img * g.a_bstride + (size_t)(16 * tile) * P;
+            aoff[u] = (unsigned)rr * (unsigned)P;
+        }
+#pragma unroll
+        for (int t = 0; t < TJ; ++t) {
+            const int tile = (tjg * TJ + t < ntb) ? tjg * TJ + t : ntb - 1;
+            const int rr = (16 * tile + r < g.Cb) ? r : g.Cb - 1 - 16 * tile;
+            const bool second = 16 * tile >= g.Cb1;                                // launch_gram2: Cb1 % 16 == 0 when there are two inputs
+            bbase[t] = second ? g.b2 + (size_t)img * g.b2_bstride + (size_t)(16 * tile - g.Cb1) * P : g.b + (size_t)img * g.b_bstride + (size_t)(16 * tile) * P;
+            boff[t] = (unsigned)rr * (unsigned)P;
+        }
     }
     f32x4 acc[NTAP * NA][TJ];       // [tap * NA + A tile]
 #pragma unroll
@@ -81,6 +126,13 @@ __global__ void __launch_bounds__(256) gram2_kernel(Gram2Args g) {
         const int nn = n0 + 4 * kq;
         q.ok = nn < n_hi;
         const int n = q.ok ? nn : n_lo;
+        if constexpr (NTAP == 1) {
+#pragma unroll
+            for (int u = 0; u < NA; ++u) q.a[u] = ld4(abase[u] + (aoff[u] + (unsigned)n));
+#pragma unroll
+            for (int t = 0; t < TJ; ++t) q.c[t][0] = ld4(bbase[t] + (boff[t] + (unsigned)n));
+            return;
+        }
         const int y = n / w, x = n - y * w;
 #pragma unroll
         for (int u = 0; u < NA; ++u) q.a[u] = ld4(arow[u] + n);
@@ -106,9 +158,26 @@ __global__ void __launch_bounds__(256) gram2_kernel(Gram2Args g) {
     auto compute = [&](const Step& q) {
         float aa[NA][4];
 #pragma unroll
-        for (int u = 0; u < NA; ++u) { aa[u][0] = q.ok ? q.a[u].x : 0.f; aa[u][1] = q.ok ? q.a[u].y : 0.f; aa[u][2] = q.ok ? q.a[u].z : 0.f; aa[u][3] = q.ok ? q.a[u].w : 0.f; }
+        for (int u = 0; u < NA; ++u) { aa[u][0] = q.a[u].x; aa[u][1] = q.a[u].y; aa[u][2] = q.a[u].z; aa[u][3] = q.a[u].w; }
+        if constexpr (NTAP != 1 || MASK) {   // a zero A value silences its products: B needs no mask in the single-tap form
+#pragma unroll
+            for (int u = 0; u < NA; ++u)
+#pragma unroll
+                for (int m = 0; m < 4; ++m) aa[u][m] = q.ok ? aa[u][m] : 0.f;
+        }
 #pragma unroll
         for (int u = 0; u < NA; ++u) bsum[u] += (aa[u][0] + aa[u][1]) + (aa[u][2] + aa[u][3]);
+        if constexpr (NTAP == 1) {
+#pragma unroll
+            for (int t = 0; t < TJ; ++t) {
+                const float bv[4] = {q.c[t][0].x, q.c[t][0].y, q.c[t][0].z, q.c[t][0].w};
+#pragma unroll
+                for (int u = 0; u < NA; ++u)
+#pragma unroll
+                    for (int m = 0; m < 4; ++m) acc[u][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(aa[u][m], bv[m], acc[u][t], 0, 0, 0);
+            }
+            return;
+        }
 #pragma unroll
         for (int t = 0; t < TJ; ++t) {
             float v[NROW][6];
@@ -138,17 +207,27 @@ __global__ void __launch_bounds__(256) gram2_kernel(Gram2Args g) {
     };
     // the loop is wave-uniform: an MFMA takes its operands from ALL 64 lanes whatever EXEC says, so lanes past the end of the
     // slab stay in the loop and feed zeros (clamped address, masked value)
+    // Steps of this wave: k = 0 .. nsteps - 1 at pixels n_lo + 16 wave + 64 k (scalar loop control).  The loads of step k + 1 are
+    // issued UNCONDITIONALLY before step k is multiplied (past the end they re-read the slab's first pixels: clamped address,
+    // result unused), so that no branch separates a load from the wait that belongs to it.
     Step s0, s1;
-    int n0 = n_lo + wave * 16;
-    if (n0 < n_hi) load_step(s0, n0);
-    for (; n0 < n_hi; n0 += 128) {
-        const bool more1 = n0 + 64 < n_hi;
-        if (more1) load_step(s1, n0 + 64);
+    const int first = n_lo + wave * 16;
+    const int nsteps = first < n_hi ? (n_hi - first + 63) >> 6 : 0;
+    // (the compiler barriers pin the loads where they are written: without them hipcc sinks every load_step down to the
+    // compute that uses it -- load, s_waitcnt vmcnt(0), multiply -- and the prefetch is gone)
+    if (nsteps > 0) load_step(s0, first);
+    int k = 0;
+    for (; k + 2 <= nsteps; k += 2) {           // two steps per trip, no exit in the middle: s0 / s1 stay in their registers
+        load_step(s1, first + 64 * (k + 1));
+        asm volatile("" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);      // ... and the machine scheduler from moving them down into the MFMA block
         compute(s0);
-        if (!more1) break;
-        if (n0 + 128 < n_hi) load_step(s0, n0 + 128);
+        load_step(s0, first + 64 * (k + 2));
+        asm volatile("" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
         compute(s1);
     }
+    if (k < nsteps) compute(s0);                // odd step count
     __shared__ float red[4][16][17];
 #pragma unroll
     for (int k = 0; k < NTAP * NA; ++k)
@@ -656,23 +735,29 @@ int launch_gram2(const float* a, int64_t a_bstride, int Ca, const float* b, int6
     RF_CHECK_ARG(w % 4 == 0 && aligned16(a) && aligned16(b) && a_bstride % 4 == 0 && b_bstride % 4 == 0,
                  "gram2: width %d must be a multiple of 4 and the operands 16-byte aligned", w);
     RF_CHECK_ARG(ntap == 1 || ntap == 9, "gram2: ntap must be 1 or 9");
-    RF_CHECK_ARG(ntap == 9 || sx == 0, "gram2: the single-tap form shifts rows only (sx = %d)", sx);
+    RF_CHECK_ARG(ntap == 9 || (sx == 0 && sy == 0), "gram2: the single-tap form takes no shift (sy = %d, sx = %d)", sy, sx);
+    RF_CHECK_ARG(Cb2 == 0 || Cb % 16 == 0, "gram2: a second input needs the first to hold a multiple of 16 channels (%d)", Cb);
     RF_CHECK_ARG(!db || !per_image, "gram2: the bias gradient is a sum over all images");
     RF_CHECK_ARG(Cb2 == 0 || (b2 && aligned16(b2) && b2_bstride % 4 == 0), "gram2: bad second input");
     const int Cb1 = Cb;
     Cb += Cb2;                                      // rows [Cb1, Cb1 + Cb2) of the input are b2's channels
-    Gram2Args g{a, a_bstride, Ca, b, b_bstride, Cb, Cb2 ? b2 : b, Cb2 ? b2_bstride : b_bstride, Cb1, partial, B, h, w, sy, sx, 0, 0, nullptr};
-    const int na = gram2_na(Ca, ntap), tj = gram2_tj(Cb, ntap);
+    Gram2Args g{a, a_bstride, Ca, b, b_bstride, Cb, Cb2 ? b2 : b, Cb2 ? b2_bstride : b_bstride, Cb1, partial, B, h, w, sy, sx, 0, 0, nullptr, 0, 0, 0};
+    // P % 16 != 0 (no frame of the reference's pipeline): the masked single-tap instantiations exist for one A tile only
+    const bool masked = ntap == 1 && ((h * w) & 15) != 0;
+    const int na = masked ? 1 : gram2_na(Ca, ntap), tj = gram2_tj(Cb, ntap);
     gram2_slabs(B, h * w, cdiv(Ca, 16 * na) * cdiv(Cb, 16 * tj), &g.slab_px, &g.slabs_per_image);
     const int nslab = B * g.slabs_per_image;
+    g.nslab = nslab; g.nty = cdiv(Ca, 16 * na); g.ntz = cdiv(Cb, 16 * tj);
     const size_t n = (size_t)ntap * Ca * Cb;
     if (db) g.bias_partial = partial + (size_t)nslab * n;
     ProfScope prof(st, ntap == 1 ? "gram2_kernel<1>" : "gram2_kernel<9>", 2.0 * ntap * Ca * Cb * (double)B * h * w, 4.0 * (double)B * h * w * (Ca + Cb));
-    const dim3 grid1((unsigned)nslab, (unsigned)cdiv(Ca, 16 * na), (unsigned)cdiv(Cb, 16 * tj));
-#define RF_G2(NA_, TJ_) gram2_kernel<1, NA_, TJ_><<<grid1, 256, 0, st>>>(g)
+    const dim3 grid1((unsigned)(cdiv(nslab, 8) * 8 * g.nty * g.ntz));
+#define RF_G2(NA_, TJ_) gram2_kernel<1, NA_, TJ_, false><<<grid1, 256, 0, st>>>(g)
 #define RF_G2_TJ(NA_) do { if (tj == 2) RF_G2(NA_, 2); else RF_G2(NA_, 4); } while (0)
-    if (ntap == 9 && na == 2) gram2_kernel<9, 2, 1><<<dim3((unsigned)nslab, (unsigned)cdiv(Ca, 32), (unsigned)cdiv(Cb, 16)), 256, 0, st>>>(g);
-    else if (ntap == 9) gram2_kernel<9, 1, 1><<<dim3((unsigned)nslab, (unsigned)cdiv(Ca, 16), (unsigned)cdiv(Cb, 16)), 256, 0, st>>>(g);
+    if (ntap == 9 && na == 2) gram2_kernel<9, 2, 1><<<grid1, 256, 0, st>>>(g);
+    else if (ntap == 9) gram2_kernel<9, 1, 1><<<grid1, 256, 0, st>>>(g);
+    else if (masked && tj == 2) gram2_kernel<1, 1, 2, true><<<grid1, 256, 0, st>>>(g);
+    else if (masked) gram2_kernel<1, 1, 4, true><<<grid1, 256, 0, st>>>(g);
     else if (na == 6) RF_G2_TJ(6);
     else if (na == 4) RF_G2_TJ(4);
     else if (na == 3) RF_G2_TJ(3);

@@ -246,7 +246,12 @@ int b_conv1x1_dx(const Ctx& c, const float* dy, int Cout, const float* w, int K,
 // (x2 / Cx2: the layer's input is cat(x, x2) along channels, read in place)
 int b_conv1x1_dw(const Ctx& c, const float* dy, int Cout, const float* x, int Cx, float* dW, int ld, int col0, float* db, int hh, int ww,
                  int64_t dy_bstride = 0, const float* x2 = nullptr, int Cx2 = 0) {
-    return launch_gram2(dy, dy_bstride ? dy_bstride : (int64_t)Cout * hh * ww, Cout, x, (int64_t)Cx * hh * ww, Cx, dW + col0, ld, c.p->part, c.B, hh, ww,
+    const int64_t dys = dy_bstride ? dy_bstride : (int64_t)Cout * hh * ww;
+    if (Cx2 && Cx % 16 != 0) {       // the two-source contraction cuts the inputs at a tile boundary: otherwise one pass per input
+        RF_TRY(launch_gram2(dy, dys, Cout, x, (int64_t)Cx * hh * ww, Cx, dW + col0, ld, c.p->part, c.B, hh, ww, 1, 0, 0, 0, 0, 1, c.st, col0 == 0 ? db : nullptr));
+        return launch_gram2(dy, dys, Cout, x2, (int64_t)Cx2 * hh * ww, Cx2, dW + col0 + Cx, ld, c.p->part, c.B, hh, ww, 1, 0, 0, 0, 0, 1, c.st);
+    }
+    return launch_gram2(dy, dys, Cout, x, (int64_t)Cx * hh * ww, Cx, dW + col0, ld, c.p->part, c.B, hh, ww,
                         1, 0, 0, 0, 0, 1, c.st, col0 == 0 ? db : nullptr, x2, (int64_t)Cx2 * hh * ww, Cx2);
 }
 

@@ -25,7 +25,7 @@ def main():
     acc = collections.defaultdict(lambda: collections.defaultdict(lambda: [0.0, 0]))
     for f in files:
         for row in csv.DictReader(open(f)):
-            k = re.sub(r"\(.*", "", row["Kernel_Name"].replace("void rf::", "").replace("rf::", ""))
+            k = re.sub(r"\(.*", "", row["Kernel_Name"].replace("(anonymous namespace)::", "").replace("void rf::", "").replace("void ", "").replace("rf::", ""))
             if k.startswith(("__amd", "at::", "void at::")):
                 continue
             a = acc[k][row["Counter_Name"]]

@@ -25,7 +25,7 @@ def load(path, name):
     for r in csv.DictReader(open(path)):
         if r["Counter_Name"] != name:
             continue
-        k = re.sub(r"\(.*", "", r["Kernel_Name"].replace("void rf::", "").replace("rf::", ""))
+        k = re.sub(r"\(.*", "", r["Kernel_Name"].replace("(anonymous namespace)::", "").replace("void rf::", "").replace("void ", "").replace("rf::", ""))
         acc[k][0] += float(r["Counter_Value"])
         acc[k][1] += 1
     return acc
