@@ -61,6 +61,8 @@ struct TrainPlan {
     float *wt1, *wt2;                  // on-the-fly packed / flipped weights (shapes the pack cache does not hold)
     float *pack_cache;                 // every packed weight form of the step, written by a few batched launches at its start
     float *part;                       // reduction partials
+    float *part_wg;                    // ... of the kernels on the weight-gradient stream
+    float *sb[16];                     // stage_backward's temporaries, one buffer per tensor (see there)
     float *small;                      // attention: per-image C x C matrices and packed per-image weights
     float *loss_part;
     size_t total;
@@ -163,6 +165,12 @@ int make_train_plan(const rf_handle* h, float* base, int B, int H, int W, TrainP
     p.wt1 = b.take(wt); p.wt2 = b.take(wt);
     p.pack_cache = b.take(build_pack_list(h, nullptr, nullptr, nullptr));
     p.part = b.take(max_sz(part, (size_t)B * 64 * 512));
+    p.part_wg = b.take(max_sz(part, (size_t)B * 64 * 512));
+    {   // d_pre, d_cr, d_cat, d_f2, d_f1, ln2, d_ln2, d_x1, o, d_o, d_qkv, d_qkvp, ln1, d_ln1, d_xs, d_tr   (units of U0)
+        const size_t hx = (size_t)hcx;
+        const size_t units[16] = {1, 1, 2, hx, hx, 1, 1, 1, 1, 1, 3, 3, 1, 1, 1, 1};
+        for (int k = 0; k < 16; ++k) p.sb[k] = b.take(units[k] * U0);
+    }
     p.small = b.take(small);
     p.loss_part = b.take(4096);
     p.flca_scr = b.take(fscr);
@@ -179,6 +187,24 @@ struct Ctx {
     int B;
     hipStream_t st;
     const PackMap* packs = nullptr;
+    // weight-gradient stream: inside stage_backward the dW kernels (which nothing downstream of the stage waits for) run beside the
+    // dX chain; wg == st: one stream (profiling, or the second stream could not be created)
+    hipStream_t wg = nullptr;
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+    mutable bool in_stage = false;
+    bool forked() const { return in_stage && wg != st; }
+    hipStream_t dw_stream() const { return forked() ? wg : st; }
+    float* dw_part() const { return forked() ? p->part_wg : p->part; }
+    int fork() const {                 // everything enqueued on st so far precedes what is enqueued on wg from now on
+        if (!forked()) return RF_OK;
+        if (int rc = check_hip(hipEventRecord(ev_fork, st), "weight-gradient stream fork (record)")) return rc;
+        return check_hip(hipStreamWaitEvent(wg, ev_fork, 0), "weight-gradient stream fork (wait)");
+    }
+    int join() const {                 // ... and the reverse
+        if (!forked()) return RF_OK;
+        if (int rc = check_hip(hipEventRecord(ev_join, wg), "weight-gradient stream join (record)")) return rc;
+        return check_hip(hipStreamWaitEvent(st, ev_join, 0), "weight-gradient stream join (wait)");
+    }
     float* G(const std::string& n) const { return grads + h->flat_offset[rf_param_index(h, n)]; }
     const float* pk(const float* w, int form) const {      // nullptr: not in the cache (the helper packs on the fly)
         if (!packs) return nullptr;
@@ -247,12 +273,15 @@ int b_conv1x1_dx(const Ctx& c, const float* dy, int Cout, const float* w, int K,
 int b_conv1x1_dw(const Ctx& c, const float* dy, int Cout, const float* x, int Cx, float* dW, int ld, int col0, float* db, int hh, int ww,
                  int64_t dy_bstride = 0, const float* x2 = nullptr, int Cx2 = 0) {
     const int64_t dys = dy_bstride ? dy_bstride : (int64_t)Cout * hh * ww;
+    RF_TRY(c.fork());
+    const hipStream_t ws = c.dw_stream();
+    float* part = c.dw_part();
     if (Cx2 && Cx % 16 != 0) {       // the two-source contraction cuts the inputs at a tile boundary: otherwise one pass per input
-        RF_TRY(launch_gram2(dy, dys, Cout, x, (int64_t)Cx * hh * ww, Cx, dW + col0, ld, c.p->part, c.B, hh, ww, 1, 0, 0, 0, 0, 1, c.st, col0 == 0 ? db : nullptr));
-        return launch_gram2(dy, dys, Cout, x2, (int64_t)Cx2 * hh * ww, Cx2, dW + col0 + Cx, ld, c.p->part, c.B, hh, ww, 1, 0, 0, 0, 0, 1, c.st);
+        RF_TRY(launch_gram2(dy, dys, Cout, x, (int64_t)Cx * hh * ww, Cx, dW + col0, ld, part, c.B, hh, ww, 1, 0, 0, 0, 0, 1, ws, col0 == 0 ? db : nullptr));
+        return launch_gram2(dy, dys, Cout, x2, (int64_t)Cx2 * hh * ww, Cx2, dW + col0 + Cx, ld, part, c.B, hh, ww, 1, 0, 0, 0, 0, 1, ws);
     }
-    return launch_gram2(dy, dys, Cout, x, (int64_t)Cx * hh * ww, Cx, dW + col0, ld, c.p->part, c.B, hh, ww,
-                        1, 0, 0, 0, 0, 1, c.st, col0 == 0 ? db : nullptr, x2, (int64_t)Cx2 * hh * ww, Cx2);
+    return launch_gram2(dy, dys, Cout, x, (int64_t)Cx * hh * ww, Cx, dW + col0, ld, part, c.B, hh, ww,
+                        1, 0, 0, 0, 0, 1, ws, col0 == 0 ? db : nullptr, x2, (int64_t)Cx2 * hh * ww, Cx2);
 }
 
 int b_conv3x3_dx(const Ctx& c, const float* dy, int Cout, const float* w, int Cin, float* dx, int hh, int ww) {
@@ -266,11 +295,13 @@ int b_conv3x3_dx(const Ctx& c, const float* dy, int Cout, const float* w, int Ci
 }
 
 int b_conv3x3_dw(const Ctx& c, const float* dy, int Cout, const float* x, int Cin, float* dW, float* db, int hh, int ww) {
-    return launch_gram2(dy, (int64_t)Cout * hh * ww, Cout, x, (int64_t)Cin * hh * ww, Cin, dW, Cin, c.p->part, c.B, hh, ww, 9, 0, 0, 0, 0, 1, c.st, db);
+    RF_TRY(c.fork());
+    return launch_gram2(dy, (int64_t)Cout * hh * ww, Cout, x, (int64_t)Cin * hh * ww, Cin, dW, Cin, c.dw_part(), c.B, hh, ww, 9, 0, 0, 0, 0, 1, c.dw_stream(), db);
 }
 
 int b_dw(const Ctx& c, const float* dy, const float* x, const float* w, float* dx, float* dW, float* db, int C, int hh, int ww) {
-    RF_TRY(launch_dw_wgrad(x, dy, dW, db, c.p->part, c.B, C, hh, ww, 1, c.st));
+    RF_TRY(c.fork());
+    RF_TRY(launch_dw_wgrad(x, dy, dW, db, c.dw_part(), c.B, C, hh, ww, 1, c.dw_stream()));
     const float* wf = c.pk(w, PF_T);
     if (!wf) {
         RF_TRY(launch_flip3x3(w, c.p->wt2, C, 1, 0, c.st));
@@ -477,21 +508,27 @@ int stage_backward(const Ctx& c, int i, int lvl, float* dout, float* din, int H,
     const std::string pre = "conv_tran" + std::to_string(i) + ".", t = pre + "Transformer.";
     const Stash& s = c.p->st[i];
     const size_t U = (size_t)c.B * C * Pn;
-    float *tA = c.p->tA, *tB = c.p->tB, *tC = c.p->tC, *tD = c.p->tD, *tE = c.p->tE;
+    // One buffer per tensor: the weight-gradient kernels read them from their own stream while the dX chain moves on, so nothing
+    // is overwritten inside a stage; the stage ends with a join, after which the next stage reuses the buffers.
+    float* const* sb = c.p->sb;
+    float *d_pre = sb[0], *d_cr = sb[1], *d_cat = sb[2], *d_f2 = sb[3], *d_f1 = sb[4], *ln2 = sb[5], *d_ln2 = sb[6], *d_x1 = sb[7], *o = sb[8],
+          *d_o = sb[9], *d_qkv = sb[10], *d_qkvp = sb[11], *ln1 = sb[12], *d_ln1 = sb[13], *d_xs = sb[14], *d_tr = sb[15];
+    c.in_stage = true;
     // Conv_out + LeakyReLU
-    RF_TRY(launch_ewise(dout, s.out, tA, U, 2, 0.2f, c.st));                                         // tA = d(pre-activation)
-    RF_TRY(b_conv3x3_dw(c, tA, C, s.cr, C, c.G(pre + "Conv_out.weight"), c.G(pre + "Conv_out.bias"), hh, ww));
-    RF_TRY(b_conv3x3_dx(c, tA, C, P(h, pre + "Conv_out.weight"), C, tB, hh, ww));                     // tB = dcr
+    RF_TRY(launch_ewise(dout, s.out, d_pre, U, 2, 0.2f, c.st));                                      // d(pre-activation)
+    RF_TRY(b_conv3x3_dw(c, d_pre, C, s.cr, C, c.G(pre + "Conv_out.weight"), c.G(pre + "Conv_out.bias"), hh, ww));
+    RF_TRY(b_conv3x3_dx(c, d_pre, C, P(h, pre + "Conv_out.weight"), C, d_cr, hh, ww));
     // channel_reduce over cat[xs, trans]
-    RF_TRY(b_conv1x1_dw(c, tB, C, s.xs, C, c.G(pre + "channel_reduce.weight"), 2 * C, 0, c.G(pre + "channel_reduce.bias"), hh, ww, 0, s.trans, C));
-    RF_TRY(b_conv1x1_dx(c, tB, C, P(h, pre + "channel_reduce.weight"), 2 * C, tC, Pn));               // tC = [dxs ; dtrans] per image
-    // dxs and dtrans are read in place as channel slices of tC (image stride 2C Pn) by the kernels that take a stride; only the
-    // plain variant's element-wise LeakyReLU adjoint needs contiguous halves (tA = dxs, tD = dtrans)
-    const float* dtr = tC + (size_t)C * Pn;
-    int64_t dtr_bs = (int64_t)2 * C * Pn;
+    RF_TRY(b_conv1x1_dw(c, d_cr, C, s.xs, C, c.G(pre + "channel_reduce.weight"), 2 * C, 0, c.G(pre + "channel_reduce.bias"), hh, ww, 0, s.trans, C));
+    RF_TRY(b_conv1x1_dx(c, d_cr, C, P(h, pre + "channel_reduce.weight"), 2 * C, d_cat, Pn));           // d_cat = [dxs ; dtrans] per image
+    // dxs and dtrans are read in place as channel slices of d_cat (image stride 2C Pn) by the kernels that take a stride; only the
+    // plain variant's element-wise LeakyReLU adjoint (and a LayerNorm shape without the fused kernel) needs contiguous halves
+    const float* dxs = d_cat;
+    const float* dtr = d_cat + (size_t)C * Pn;
+    int64_t half_bs = (int64_t)2 * C * Pn;
     if (cfg.variant != RF_VARIANT_FLCA || !ln_bwd_fused_shape(C, Pn)) {
-        RF_TRY(launch_split_halves(tC, tA, tD, c.B, C, Pn, c.st));
-        dtr = tD; dtr_bs = (int64_t)C * Pn;
+        RF_TRY(launch_split_halves(d_cat, d_xs, d_tr, c.B, C, Pn, c.st));
+        dxs = d_xs; dtr = d_tr; half_bs = (int64_t)C * Pn;
     }
     if (cfg.variant == RF_VARIANT_FLCA) {
         const std::string f = pre + "FLCA.";
@@ -500,26 +537,24 @@ int stage_backward(const Ctx& c, int i, int lvl, float* dout, float* din, int H,
         const float* prm[10];
         float* grd[10];
         for (int k = 0; k < 10; ++k) { prm[k] = P(h, f + names[k]); grd[k] = c.G(f + names[k]); }
-        RF_TRY(launch_flca_backward(s.in, c.p->guide[lvl], s.xraw, dtr == tD ? tA : tC, dtr == tD ? (int64_t)C * Pn : (int64_t)2 * C * Pn, s.ch, s.pool, flca_nblk(hh, ww), prm, grd, din, 0,
+        RF_TRY(launch_flca_backward(s.in, c.p->guide[lvl], s.xraw, dxs, half_bs, s.ch, s.pool, flca_nblk(hh, ww), prm, grd, din, 0,
                                     c.p->flca_scr, c.B, C, hh, ww, c.st));                             // din = branch part
     } else {
         // conv branch
-        if (cfg.branch_lrelu) RF_TRY(launch_ewise(tA, s.xs, tA, U, 2, 0.2f, c.st));
-        RF_TRY(b_conv3x3_dw(c, tA, C, s.in, C, c.G(pre + "conv.weight"), c.G(pre + "conv.bias"), hh, ww));
-        RF_TRY(b_conv3x3_dx(c, tA, C, P(h, pre + "conv.weight"), C, din, hh, ww));                    // din = branch part
+        if (cfg.branch_lrelu) RF_TRY(launch_ewise(d_xs, s.xs, d_xs, U, 2, 0.2f, c.st));
+        RF_TRY(b_conv3x3_dw(c, d_xs, C, s.in, C, c.G(pre + "conv.weight"), c.G(pre + "conv.bias"), hh, ww));
+        RF_TRY(b_conv3x3_dx(c, d_xs, C, P(h, pre + "conv.weight"), C, din, hh, ww));                  // din = branch part
     }
     // FFN:  trans = x1 + pw2(gelu(dw(pw1(LN2(x1)))))          dtr = dtrans (also the residual part of dx1)
-    RF_TRY(b_conv1x1_dw(c, dtr, C, s.g, hc, c.G(t + "ffn.pointwise2.weight"), hc, 0, c.G(t + "ffn.pointwise2.bias"), hh, ww, dtr_bs));
-    RF_TRY(b_conv1x1_dx(c, dtr, C, P(h, t + "ffn.pointwise2.weight"), hc, tB, Pn, nullptr, dtr_bs));  // tB = dg
-    RF_TRY(launch_ewise(tB, s.f2, tB, (size_t)c.B * hc * Pn, 1, 0.f, c.st));                          // tB = df2
-    RF_TRY(b_dw(c, tB, s.f1, P(h, t + "ffn.depthwise.weight"), tA, c.G(t + "ffn.depthwise.weight"), c.G(t + "ffn.depthwise.bias"), hc, hh, ww));   // tA = df1
-    RF_TRY(launch_layernorm2d(s.x1, tB, P(h, t + "norm2.body.weight"), P(h, t + "norm2.body.bias"), 1e-5f, c.B, C, Pn, c.st));   // tB = LN2(x1)
-    RF_TRY(b_conv1x1_dw(c, tA, hc, tB, C, c.G(t + "ffn.pointwise1.weight"), C, 0, c.G(t + "ffn.pointwise1.bias"), hh, ww));
-    RF_TRY(b_conv1x1_dx(c, tA, hc, P(h, t + "ffn.pointwise1.weight"), C, tB, Pn));                    // tB = d LN2 out
-    if (dtr == tD)
-        RF_TRY(launch_ln_bwd(s.x1, tB, P(h, t + "norm2.body.weight"), tD, c.G(t + "norm2.body.weight"), c.p->part, c.B, C, Pn, 1e-5f, 1, 1, c.st));
-    else       // tD = dx1 = dtrans + (LayerNorm adjoint), dtrans read in place
-        RF_TRY(launch_ln_bwd(s.x1, tB, P(h, t + "norm2.body.weight"), tD, c.G(t + "norm2.body.weight"), c.p->part, c.B, C, Pn, 1e-5f, 0, 1, c.st, dtr, dtr_bs));
+    RF_TRY(b_conv1x1_dw(c, dtr, C, s.g, hc, c.G(t + "ffn.pointwise2.weight"), hc, 0, c.G(t + "ffn.pointwise2.bias"), hh, ww, half_bs));
+    RF_TRY(b_conv1x1_dx(c, dtr, C, P(h, t + "ffn.pointwise2.weight"), hc, d_f2, Pn, nullptr, half_bs));   // dg ...
+    RF_TRY(launch_ewise(d_f2, s.f2, d_f2, (size_t)c.B * hc * Pn, 1, 0.f, c.st));                      // ... -> df2, in place
+    RF_TRY(b_dw(c, d_f2, s.f1, P(h, t + "ffn.depthwise.weight"), d_f1, c.G(t + "ffn.depthwise.weight"), c.G(t + "ffn.depthwise.bias"), hc, hh, ww));
+    RF_TRY(launch_layernorm2d(s.x1, ln2, P(h, t + "norm2.body.weight"), P(h, t + "norm2.body.bias"), 1e-5f, c.B, C, Pn, c.st));   // LN2(x1) again
+    RF_TRY(b_conv1x1_dw(c, d_f1, hc, ln2, C, c.G(t + "ffn.pointwise1.weight"), C, 0, c.G(t + "ffn.pointwise1.bias"), hh, ww));
+    RF_TRY(b_conv1x1_dx(c, d_f1, hc, P(h, t + "ffn.pointwise1.weight"), C, d_ln2, Pn));               // d LN2 out
+    // d_x1 = dtrans + (LayerNorm adjoint), dtrans read in place
+    RF_TRY(launch_ln_bwd(s.x1, d_ln2, P(h, t + "norm2.body.weight"), d_x1, c.G(t + "norm2.body.weight"), c.p->part, c.B, C, Pn, 1e-5f, 0, 1, c.st, dtr, half_bs));
     // attention:  x1 = in + W_out (A v) + b          (the residual din += dx1 rides on the last kernel of the stage)
     const size_t CC = (size_t)C * C;
     const size_t per = 3 * CC + packed1x1_floats(2 * C, 2 * C) + 2 * packed1x1_floats(C, C);
@@ -529,34 +564,53 @@ int stage_backward(const Ctx& c, int i, int lvl, float* dout, float* din, int H,
     float* at = m2 + packed1x1_floats(2 * C, 2 * C);
     float* ap = at + packed1x1_floats(C, C);
     const float* v = s.qkv + (size_t)2 * C * Pn;
-    {   // tA = o = blockdiag(A) v
+    {   // o = blockdiag(A) v
         Conv1x1Args a{};
         a.x1 = v; a.C1 = C; a.x1_bstride = (int64_t)3 * C * Pn; a.wp = ap; a.wp_bstride = (int64_t)per;
-        a.out = tA; a.out_bstride = (int64_t)C * Pn; a.Cout = C; a.B = c.B; a.P = Pn; a.w = ww;
+        a.out = o; a.out_bstride = (int64_t)C * Pn; a.Cout = C; a.B = c.B; a.P = Pn; a.w = ww;
         RF_TRY(launch_conv1x1(a, c.st));
     }
-    RF_TRY(b_conv1x1_dw(c, tD, C, tA, C, c.G(t + "attn.project_out.weight"), C, 0, c.G(t + "attn.project_out.bias"), hh, ww));
-    RF_TRY(b_conv1x1_dx(c, tD, C, P(h, t + "attn.project_out.weight"), C, tB, Pn));                   // tB = do
-    RF_TRY(launch_gram2(tB, (int64_t)C * Pn, C, v, (int64_t)3 * C * Pn, C, c.p->small, C, c.p->part, c.B, hh, ww, 1, 0, 0, 1, per, 0, c.st));   // dA per image
+    RF_TRY(b_conv1x1_dw(c, d_x1, C, o, C, c.G(t + "attn.project_out.weight"), C, 0, c.G(t + "attn.project_out.bias"), hh, ww));
+    RF_TRY(b_conv1x1_dx(c, d_x1, C, P(h, t + "attn.project_out.weight"), C, d_o, Pn));
+    // dA per image: on the dX chain (the softmax adjoint waits for it)
+    RF_TRY(launch_gram2(d_o, (int64_t)C * Pn, C, v, (int64_t)3 * C * Pn, C, c.p->small, C, c.p->part, c.B, hh, ww, 1, 0, 0, 1, per, 0, c.st));
     RF_TRY(attn_small(c, s, P(h, t + "attn.temperature"), C, heads, 0, c.G(t + "attn.temperature")));
-    {   // tC = d(qkv): [dq ; dk] = M2 [q ; k],  dv = blockdiag(A^T) do
+    {   // d(qkv): [dq ; dk] = M2 [q ; k],  dv = blockdiag(A^T) do
         Conv1x1Args a{};
         a.x1 = s.qkv; a.C1 = 2 * C; a.x1_bstride = (int64_t)3 * C * Pn; a.wp = m2; a.wp_bstride = (int64_t)per;
-        a.out = tC; a.out_bstride = (int64_t)3 * C * Pn; a.Cout = 2 * C; a.B = c.B; a.P = Pn; a.w = ww;
+        a.out = d_qkv; a.out_bstride = (int64_t)3 * C * Pn; a.Cout = 2 * C; a.B = c.B; a.P = Pn; a.w = ww;
         RF_TRY(launch_conv1x1(a, c.st));
         Conv1x1Args d{};
-        d.x1 = tB; d.C1 = C; d.x1_bstride = (int64_t)C * Pn; d.wp = at; d.wp_bstride = (int64_t)per;
-        d.out = tC + (size_t)2 * C * Pn; d.out_bstride = (int64_t)3 * C * Pn; d.Cout = C; d.B = c.B; d.P = Pn; d.w = ww;
+        d.x1 = d_o; d.C1 = C; d.x1_bstride = (int64_t)C * Pn; d.wp = at; d.wp_bstride = (int64_t)per;
+        d.out = d_qkv + (size_t)2 * C * Pn; d.out_bstride = (int64_t)3 * C * Pn; d.Cout = C; d.B = c.B; d.P = Pn; d.w = ww;
         RF_TRY(launch_conv1x1(d, c.st));
     }
-    RF_TRY(b_dw(c, tC, s.qkvp, P(h, t + "attn.qkv_dwconv.weight"), tA, c.G(t + "attn.qkv_dwconv.weight"), c.G(t + "attn.qkv_dwconv.bias"), 3 * C, hh, ww));   // tA = dqkvp
-    RF_TRY(launch_layernorm2d(s.in, tB, P(h, t + "norm1.body.weight"), P(h, t + "norm1.body.bias"), 1e-5f, c.B, C, Pn, c.st));   // tB = LN1(in)
-    RF_TRY(b_conv1x1_dw(c, tA, 3 * C, tB, C, c.G(t + "attn.qkv.weight"), C, 0, c.G(t + "attn.qkv.bias"), hh, ww));
-    RF_TRY(b_conv1x1_dx(c, tA, 3 * C, P(h, t + "attn.qkv.weight"), C, tB, Pn));                       // tB = d LN1 out
+    RF_TRY(b_dw(c, d_qkv, s.qkvp, P(h, t + "attn.qkv_dwconv.weight"), d_qkvp, c.G(t + "attn.qkv_dwconv.weight"), c.G(t + "attn.qkv_dwconv.bias"), 3 * C, hh, ww));
+    RF_TRY(launch_layernorm2d(s.in, ln1, P(h, t + "norm1.body.weight"), P(h, t + "norm1.body.bias"), 1e-5f, c.B, C, Pn, c.st));   // LN1(in) again
+    RF_TRY(b_conv1x1_dw(c, d_qkvp, 3 * C, ln1, C, c.G(t + "attn.qkv.weight"), C, 0, c.G(t + "attn.qkv.bias"), hh, ww));
+    RF_TRY(b_conv1x1_dx(c, d_qkvp, 3 * C, P(h, t + "attn.qkv.weight"), C, d_ln1, Pn));                // d LN1 out
     // din (branch part) += dx1 (residual of x1 = in + attention) + (LayerNorm adjoint)
-    RF_TRY(launch_ln_bwd(s.in, tB, P(h, t + "norm1.body.weight"), din, c.G(t + "norm1.body.weight"), c.p->part, c.B, C, Pn, 1e-5f, 1, 1, c.st, tD, (int64_t)C * Pn));
-    (void)tE; (void)U;
+    RF_TRY(launch_ln_bwd(s.in, d_ln1, P(h, t + "norm1.body.weight"), din, c.G(t + "norm1.body.weight"), c.p->part, c.B, C, Pn, 1e-5f, 1, 1, c.st, d_x1, (int64_t)C * Pn));
+    RF_TRY(c.join());
+    c.in_stage = false;
     return RF_OK;
+}
+
+// second stream of the step (the handle's branch stream and events, rf_handle.h): none while profiling -- the per-kernel brackets
+// assume one stream -- or when it cannot be created
+hipStream_t train_side_stream(rf_handle* h, hipStream_t st) {
+    if (h->side_failed || profiling_active()) return st;
+    if (!h->side) {
+        if (hipStreamCreateWithFlags(&h->side, hipStreamNonBlocking) != hipSuccess ||
+            hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming) != hipSuccess ||
+            hipEventCreateWithFlags(&h->ev_join, hipEventDisableTiming) != hipSuccess) {
+            (void)hipGetLastError();
+            h->side_failed = true;
+            h->side = nullptr;
+            return st;
+        }
+    }
+    return h->side;
 }
 
 }  // namespace
@@ -656,6 +710,8 @@ int rf_train_step(rf_handle* h, const float* in, const float* gt, float* grads, 
     build_pack_list(h, p.pack_cache, &pack_list, &pack_map);
     RF_TRY(launch_pack_batch(pack_list.data(), (int)pack_list.size(), st));
     c.packs = &pack_map;
+    c.wg = train_side_stream(h, st);
+    c.ev_fork = h->ev_fork; c.ev_join = h->ev_join;
 
     // ------------------------------------------------------------------ forward
     RF_TRY(launch_pixel_unshuffle2(in, p.x4, B, 1, H, W, st));
