@@ -72,6 +72,10 @@ int run_transformer(const TbParams& p, const float* in, float* out, float* ws, c
         q.wp = p.qkv_wp; q.wp3 = p.qkv_wp3; q.bias = p.qkv_b;
         q.ln_w = p.ln1_w; q.ln_b = p.ln1_b; q.ln_eps = 1e-5f;
         q.out = bufA; q.out_bstride = (int64_t)3 * C * Pn; q.Cout = 3 * C; q.B = B; q.P = Pn; q.w = ww;
+        if (!conv1x1_ln_single_pass(q)) {      // LN1 as its own pass (bufB is free until the depthwise kernel writes it)
+            RF_TRY(launch_layernorm2d(in, bufB, p.ln1_w, p.ln1_b, 1e-5f, B, C, Pn, st));
+            q.x1 = bufB; q.ln_w = nullptr; q.ln_b = nullptr;
+        }
         RF_TRY(launch_conv1x1(q, st));
 
         if (!no_fuse && attn_mid_supported(C, heads, hh, ww)) {
@@ -122,6 +126,10 @@ int run_transformer(const TbParams& p, const float* in, float* out, float* ws, c
         f1.wp = p.pw1_wp; f1.wp3 = p.pw1_wp3; f1.bias = p.pw1_b;
         f1.ln_w = p.ln2_w; f1.ln_b = p.ln2_b; f1.ln_eps = 1e-5f;
         f1.out = bufA; f1.out_bstride = (int64_t)hc * Pn; f1.Cout = hc; f1.B = B; f1.P = Pn; f1.w = ww;
+        if (!conv1x1_ln_single_pass(f1)) {     // LN2 as its own pass (bufB: the projection GEMM has consumed v)
+            RF_TRY(launch_layernorm2d(x1, bufB, p.ln2_w, p.ln2_b, 1e-5f, B, C, Pn, st));
+            f1.x1 = bufB; f1.ln_w = nullptr; f1.ln_b = nullptr;
+        }
         RF_TRY(launch_conv1x1(f1, st));
 
         DwConvArgs d2{};

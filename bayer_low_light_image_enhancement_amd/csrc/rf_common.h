@@ -191,6 +191,7 @@ struct Conv1x1Args {
     int act;               // 0 none, 1 LeakyReLU(0.2), 2 ReLU, 3 LeakyReLU(0.1), 4 clamp to [0, 1e4] (FEB, blocks.py:14-30)
 };
 int launch_conv1x1(const Conv1x1Args& a, hipStream_t st);
+bool conv1x1_ln_single_pass(const Conv1x1Args& a);   // false: cheaper as layernorm2d + the plain GEMM (the prologue would re-read x per output group)
 
 // ---- conv3x3 (rf_conv3x3.hip)
 struct Conv3x3Args {

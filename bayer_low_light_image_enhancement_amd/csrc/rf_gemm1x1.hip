@@ -856,6 +856,15 @@ static bool b3_supported(const Conv1x1Args& a) {
            (a.C3 == 0 || a.C2 % 32 == 0) && (!a.ln_w || (K <= kStreamLnMaxK && a.C3 == 0)) && aligned16(a.wp3) && (a.wp3_bstride % 4 == 0);
 }
 
+// Does the LayerNorm prologue of this GEMM read x once?  Yes on the split-once bf16x3 kernel (K = 64 / 128 / 256) and on the
+// resident-input kernels (K <= 64).  The streaming kernels re-read and re-normalise their pixels once per group of 64-96 output
+// channels (RawFormer-L level 3, K = 512 -> 1536: 24 passes, 0.77 ms for a 0.2 ms product; every level of RawFormer-B, K = 96 /
+// 192 / 384): their callers run layernorm2d first and the plain GEMM on its output (rf_block.hip).
+bool conv1x1_ln_single_pass(const Conv1x1Args& a) {
+    int nco = 0;
+    return !a.ln_w || a.C1 + a.C2 <= 64 || (a.wp3 != nullptr && b3_ln_supported(a, &nco));
+}
+
 int launch_conv1x1(const Conv1x1Args& a, hipStream_t st) {
     RF_CHECK_ARG(a.B > 0 && a.P > 0 && a.C1 > 0 && a.C2 >= 0 && a.Cout > 0, "conv1x1: bad sizes B=%d P=%d C1=%d C2=%d Cout=%d",
                  a.B, a.P, a.C1, a.C2, a.Cout);
