@@ -28,7 +28,7 @@ def bucket_bounds(n: int, bucket_floats: int):
 
 
 def allreduce_flat(flat: torch.Tensor, group=None, bucket_floats: int = 1 << 20):
-    """Sum ``flat`` over the ranks in buckets (async, waited at the end).  13.4 MB of RawFormer-S gradients = 4 buckets of
+    """Sum ``flat`` over the ranks in buckets (async, waited at the end).  9.9 MB of RawFormer-S gradients = 3 buckets of
     4 MiB: large enough for xGMI links, small enough that the first bucket is on the wire while the others queue."""
     import torch.distributed as dist
     if not dist.is_initialized() or dist.get_world_size(group) == 1:

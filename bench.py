@@ -193,22 +193,35 @@ def _latest_profile(suffix: str, workload: str):
         return None
 
 
+def _pmc_record(kernels: dict, key: str, field: str, weight: str):
+    """``field`` of the kernel ``key``; a bracket key that names a kernel family by its first template argument only (the
+    library's ``gram2_kernel<1>`` covers rocprof's ``gram2_kernel<1, 6, 2, false>`` ...) is the launch-weighted mean of the family."""
+    if key in kernels:
+        return kernels[key].get(field)
+    if key.endswith(">"):
+        fam = [v for k, v in kernels.items() if k.startswith(key[:-1] + ",")]
+        tot = sum(v.get(weight, 0) for v in fam)
+        if fam and tot:
+            val = sum(v[field] * v.get(weight, 0) for v in fam if v.get(field) is not None) / tot
+            return round(val, 4) if val < 10 else int(val)
+    return None
+
+
 def pmc_traffic(kernel, workload):
     """HBM bytes per launch of ``kernel`` from the committed rocprofv3 PMC passes of this same command and workload
     (profiles/*_traffic_<workload>.json, made by tools/traffic.py: FETCH_SIZE and WRITE_SIZE in separate passes, gfx950
     corrections applied).  PMC counters cannot be read from inside the process; None when no file covers the workload or the
     kernel is not in it."""
     d = _latest_profile("traffic", workload)
-    rec = (d or {}).get("kernels", {}).get(kernel)
-    return rec["hbm_bytes_per_launch"] if rec else None
+    rec = _pmc_record((d or {}).get("kernels", {}), kernel, "hbm_bytes_per_launch", "launches_sampled")
+    return rec
 
 
 def pmc_mfma_util(kernel, workload):
     """Matrix-pipe busy fraction of ``kernel`` from the committed SQ-counter pass (profiles/*_mfma_util_<workload>.json,
     made by tools/mfma_util.py from ``rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES ... GRBM_GUI_ACTIVE``)."""
     d = _latest_profile("mfma_util", workload)
-    rec = (d or {}).get("kernels", {}).get(kernel)
-    return rec.get("mfma_busy_frac") if rec else None
+    return _pmc_record((d or {}).get("kernels", {}), kernel, "mfma_busy_frac", "dispatches")
 
 
 def host_cores() -> int:
