@@ -873,6 +873,8 @@ int fused_attn_plan(int h, int w, int* nslab, size_t* partial_floats, int B, int
                                                 // (8 tiles: 131 us per launch for one frame, 4 tiles: 75 us; a batch of 8 pays
                                                 // 0.6 %); depends on the image only, never on B: an image's reduction order is
                                                 // batch-invariant
+    if (ntiles <= 256) ns = ntiles;             // frames up to 256 x 256 packed: one tile per workgroup (a workgroup's tiles are a
+                                                // chain of ~15 us each: 62 -> 25 us per launch for one 128 x 128 frame)
     if (ns < 1) ns = 1;
     *nslab = ns;
     *partial_floats = (size_t)B * ns * (C / 16) * 16 * 66;

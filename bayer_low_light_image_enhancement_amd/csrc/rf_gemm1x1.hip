@@ -733,7 +733,7 @@ __global__ void __launch_bounds__(256, KB <= 4 ? 2 : 1) conv1x1_b3_ln_kernel(Con
 
     // ---- output tiles of this wave, NCO at a time
     for (int chunk = 0; chunk * NCO < tpw; ++chunk) {
-        const int t0 = wave * tpw + chunk * NCO;
+        const int t0 = ((int)blockIdx.z * 4 + wave) * tpw + chunk * NCO;    // blockIdx.z: output-channel split of small launches
         f32x4 acc[NCO][4];
 #pragma unroll
         for (int t = 0; t < NCO; ++t)
@@ -896,12 +896,21 @@ int launch_conv1x1(const Conv1x1Args& a, hipStream_t st) {
         if (gx > 4096) gx = 4096;
         conv1x1_scalar_kernel<<<dim3((unsigned)gx, (unsigned)a.B), 256, 0, st>>>(a);
     } else if (int nco_ln = 0; b3_ok && b3_ln_supported(a, &nco_ln)) {
-        const int kb = K / 32, tpw = a.Cout / 64;
+        const int kb = K / 32;
+        int tpw = a.Cout / 64;
         const int slots = (kb <= 4 ? 2 : 1) * 256;                // resident workgroups (LDS: 31 / 55 / 104 KB; registers: 2 per CU)
         int gx = slots / a.B;
         gx = gx < 1 ? 1 : gx;
         gx = gx < cdiv(a.P, 64) ? gx : cdiv(a.P, 64);
-        dim3 grid((unsigned)gx, (unsigned)a.B, 1);
+        // one small frame (levels 2-3: 4-64 pixel tiles): a workgroup's waves walk tpw / NCO chunks of output tiles one after the
+        // other, each a chain of K-block steps -- split the output channels over blockIdx.z (every workgroup normalises its
+        // 64 pixels again: K x 64 values) until the launch has a few hundred workgroups.  Same arithmetic per output: same bits.
+        int zs = 1;
+        if ((long)gx * a.B < 128)
+            for (int z = tpw / nco_ln; z > 1; --z)
+                if ((tpw / nco_ln) % z == 0 && (long)gx * a.B * z <= 512) { zs = z; break; }
+        tpw /= zs;
+        dim3 grid((unsigned)gx, (unsigned)a.B, (unsigned)zs);
         snprintf(key, sizeof(key), "conv1x1_b3_ln_kernel<%d, %d>", kb, nco_ln);
         ProfScope prof(st, key, work_flops, work_bytes);
         if (kb == 2) {
