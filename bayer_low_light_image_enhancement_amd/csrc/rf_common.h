@@ -207,8 +207,14 @@ struct Conv3x3Args {
     int unshuffle_in;      // read the input through the Bayer pack (a1)
     int clamp_in;          // clamp input to [0,1] while loading
     int clamp_out;         // clamp output to [0,1] before storing
+    // optional scratch for the input-channel split of small launches (rf_conv3x3.hip, KS): conv3x3_ksplit_floats() floats whose
+    // first 4096 are zero before the first launch (the kernels leave them zero); nullptr = never split.  One launch at a time.
+    float* ks_scratch = nullptr;
+    size_t ks_floats = 0;
 };
 int launch_conv3x3(const Conv3x3Args& a, hipStream_t st);
+size_t conv3x3_ksplit_floats(int B, int Cout, int h, int w);   // 0: launches of this size never split
+size_t conv3x3_ksplit_counter_bytes();
 
 // ---- memory-bound ops (rf_pointwise.hip)
 int launch_layernorm2d(const float* in, float* out, const float* w, const float* b, float eps,

@@ -33,11 +33,16 @@
 namespace rf {
 
 static constexpr int KC = 8;        // input channels per LDS chunk
+static constexpr int kKsCounters = 4096;   // floats at the head of Conv3x3Args::ks_scratch that hold the tickets of a K-split launch
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 
 // NWV = waves per workgroup: 8 on wide images (the 18-tap weight slice is shared by twice the waves, so that two
 // waves per SIMD fit the 160 KB of LDS with one workgroup per CU), 4 for the narrow-image tile shapes.
-template <int NCO, int LOG2_RW, int RPW, int NWV>
+// KS (small launches only, one tile per workgroup): the input-channel chunks are split over gridDim.z workgroups.  Each writes
+// its partial tile (after the output transform, before bias and activation) to scratch; the LAST one to arrive -- a ticket per
+// (image, tile, output group) -- adds the partials in split order (deterministic whatever the arrival order), applies bias /
+// activation / clamp and stores.  One 16 x 16 frame at level 3 is a chain of 32 chunk barriers on 4 workgroups otherwise.
+template <int NCO, int LOG2_RW, int RPW, int NWV, bool KS = false>
 __global__ void __launch_bounds__(64 * NWV, (NWV >= 8 || NCO >= 3) ? 1 : 2) conv3x3_kernel(Conv3x3Args a, int ngroups, int tiles_x, int ntiles, int vec) {
     constexpr int NTHR = 64 * NWV;
     constexpr int TAPS = 18;                 // transformed taps per k-set (3 kernel rows x 6)
@@ -68,7 +73,9 @@ __global__ void __launch_bounds__(64 * NWV, (NWV >= 8 || NCO >= 3) ? 1 : 2) conv
     const int h = a.h, w = a.w;
     const int NT = (a.Cout + 15) >> 4;
     const int t0 = grp * NCO;
-    const int nchunks = (a.Cin + KC - 1) / KC;
+    const int nchunks_all = (a.Cin + KC - 1) / KC;
+    const int ksplit = KS ? (int)gridDim.z : 1, kz = KS ? (int)blockIdx.z : 0;
+    const int ch_lo = KS ? (int)((long)kz * nchunks_all / ksplit) : 0, ch_hi = KS ? (int)((long)(kz + 1) * nchunks_all / ksplit) : nchunks_all;
     const float* xb = a.x + (size_t)b * a.x_bstride;
     const size_t chunk_stride = a.unshuffle_in ? (size_t)(KC / 4) * 4 * h * w : (size_t)KC * h * w;
 
@@ -176,7 +183,7 @@ __global__ void __launch_bounds__(64 * NWV, (NWV >= 8 || NCO >= 3) ? 1 : 2) conv
         bias_l[tid] = (a.bias && co < a.Cout) ? a.bias[co] : 0.f;
     }
     plan_tile(tile);
-    load_chunk(0);
+    load_chunk(ch_lo);
     store_chunk(0);
     __syncthreads();
     int buf = 0;
@@ -189,10 +196,10 @@ __global__ void __launch_bounds__(64 * NWV, (NWV >= 8 || NCO >= 3) ? 1 : 2) conv
             for (int t = 0; t < NCO; ++t)
 #pragma unroll
                 for (int g = 0; g < NM; ++g) acc[rr][t][g] = (f32x4){0.f, 0.f, 0.f, 0.f};
-        for (int ch = 0; ch < nchunks; ++ch) {
-            const bool last = ch + 1 == nchunks;
+        for (int ch = ch_lo; ch < ch_hi; ++ch) {
+            const bool last = ch + 1 == ch_hi;
             const bool more = !last || tile + nwg < tile_end;
-            const int nch = last ? 0 : ch + 1;
+            const int nch = last ? ch_lo : ch + 1;
             if (last && more) plan_tile(tile + nwg);
             if (more) load_chunk(nch);                  // in flight during the MFMA block below
             const float* lds_in = lds + buf * BUF;
@@ -239,23 +246,26 @@ __global__ void __launch_bounds__(64 * NWV, (NWV >= 8 || NCO >= 3) ? 1 : 2) conv
     int kq_ = kq;                      // opaque per tile: keeps the bias values and output row pointers from being
     asm volatile("" : "+v"(kq_));      // hoisted out of the tile loop (they would stay live across every MFMA block)
     const int x = ex0 + 4 * cg;
+    // output transform A^T m of the lane's F(4,3) tiles: u[r][g], channel 16 (t0 + t) + 4 kq + r, pixel x + g
+    auto transform = [&](int rr, int t, float (&u)[4][4]) {
+        const f32x4* mm = acc[rr][t];
 #pragma unroll
-    for (int rr = 0; rr < RPW; ++rr) {
-    const int y = ey0 + (wave * RPW + rr) * RW + rowj;
-    if (y >= h || x >= w) continue;
-#pragma unroll
-    for (int t = 0; t < NCO; ++t) {
-        if (t0 + t >= NT) break;
-        float v[4][4];   // [r][g]
+        for (int r = 0; r < 4; ++r) {
+            const float s12 = mm[1][r] + mm[2][r], d12 = mm[1][r] - mm[2][r], s34 = mm[3][r] + mm[4][r], d34 = mm[3][r] - mm[4][r];
+            u[r][0] = (mm[0][r] + s12) + s34;
+            u[r][1] = fmaf(2.f, d34, d12);
+            u[r][2] = fmaf(4.f, s34, s12);
+            u[r][3] = fmaf(8.f, d34, d12) + mm[5][r];
+        }
+    };
+    // bias, activation, clamp
+    auto finish = [&](int t, float (&v)[4][4]) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const float bs = bias_l[16 * t + 4 * kq_ + r];
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
-                // output transform A^T m of the lane's F(4,3) tile
-                const f32x4* mm = acc[rr][t];
-                const float s12 = mm[1][r] + mm[2][r], d12 = mm[1][r] - mm[2][r], s34 = mm[3][r] + mm[4][r], d34 = mm[3][r] - mm[4][r];
-                float u = (g == 0 ? (mm[0][r] + s12) + s34 : g == 1 ? fmaf(2.f, d34, d12) : g == 2 ? fmaf(4.f, s34, s12) : fmaf(8.f, d34, d12) + mm[5][r]) + bs;
+                float u = v[r][g] + bs;
                 if (a.act == 1) u = u > 0.f ? u : 0.2f * u;
                 else if (a.act == 2) u = fmaxf(u, 0.f);
                 else if (a.act == 3) u = gelu_fast(u);
@@ -264,6 +274,8 @@ __global__ void __launch_bounds__(64 * NWV, (NWV >= 8 || NCO >= 3) ? 1 : 2) conv
                 v[r][g] = u;
             }
         }
+    };
+    auto store_tile = [&](int t, int y, const float (&v)[4][4]) {
         const int cobase = 16 * (t0 + t) + 4 * kq_;
         if (a.store == 0) {
 #pragma unroll
@@ -299,7 +311,7 @@ __global__ void __launch_bounds__(64 * NWV, (NWV >= 8 || NCO >= 3) ? 1 : 2) conv
             }
         } else {
             // conv_out + PixelShuffle(2): GEMM row 4*c + 2*i + jj -> out[c][2y+i][2x+jj]
-            if (cobase >= a.Cout) continue;
+            if (cobase >= a.Cout) return;
             const int c = cobase >> 2;
             float* op = outb + (size_t)c * 4 * h * w;
             const int w2 = 2 * w;
@@ -320,9 +332,99 @@ __global__ void __launch_bounds__(64 * NWV, (NWV >= 8 || NCO >= 3) ? 1 : 2) conv
                     }
             }
         }
+    };
+    if constexpr (!KS) {
+#pragma unroll
+        for (int rr = 0; rr < RPW; ++rr) {
+            const int y = ey0 + (wave * RPW + rr) * RW + rowj;
+            if (y >= h || x >= w) continue;
+#pragma unroll
+            for (int t = 0; t < NCO; ++t) {
+                if (t0 + t >= NT) break;
+                float v[4][4];   // [r][g]
+                transform(rr, t, v);
+                finish(t, v);
+                store_tile(t, y, v);
+            }
+        }
+    } else {
+        // partial tiles [split][image][channel][y][x] (the launcher checks w % 4 == 0), then the ticket
+        unsigned* counter = reinterpret_cast<unsigned*>(a.ks_scratch) + ((size_t)b * ntiles + tile) * ngroups + grp;
+        float* part = a.ks_scratch + kKsCounters;
+        const size_t split_stride = (size_t)a.B * a.Cout * h * w;
+        float* mine = part + (size_t)kz * split_stride + (size_t)b * a.Cout * h * w;
+#pragma unroll
+        for (int rr = 0; rr < RPW; ++rr) {
+            const int y = ey0 + (wave * RPW + rr) * RW + rowj;
+            if (y >= h || x >= w) continue;
+#pragma unroll
+            for (int t = 0; t < NCO; ++t) {
+                if (t0 + t >= NT) break;
+                float v[4][4];
+                transform(rr, t, v);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int co = 16 * (t0 + t) + 4 * kq_ + r;
+                    if (co < a.Cout) *reinterpret_cast<float4*>(mine + ((size_t)co * h + y) * w + x) = make_float4(v[r][0], v[r][1], v[r][2], v[r][3]);
+                }
+            }
+        }
+        __shared__ unsigned ticket;
+        __threadfence();                               // the partial tile is visible device-wide before the ticket is taken
+        __syncthreads();
+        if (tid == 0) ticket = atomicAdd(counter, 1u);
+        __syncthreads();
+        if (ticket != (unsigned)(ksplit - 1)) return;  // not the last split of this tile
+        if (tid == 0) *counter = 0u;                   // ready for the next launch (stream order)
+        __threadfence();
+#pragma unroll
+        for (int rr = 0; rr < RPW; ++rr) {
+            const int y = ey0 + (wave * RPW + rr) * RW + rowj;
+            if (y >= h || x >= w) continue;
+#pragma unroll
+            for (int t = 0; t < NCO; ++t) {
+                if (t0 + t >= NT) break;
+                float v[4][4];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int co = 16 * (t0 + t) + 4 * kq_ + r;
+                    float4 sum = make_float4(0.f, 0.f, 0.f, 0.f);
+                    if (co < a.Cout) {
+                        const float* src = part + (size_t)b * a.Cout * h * w + ((size_t)co * h + y) * w + x;
+                        for (int z = 0; z < ksplit; ++z) {          // split order, whatever the arrival order
+                            const float4 pz = *reinterpret_cast<const float4*>(src + (size_t)z * split_stride);
+                            sum.x += pz.x; sum.y += pz.y; sum.z += pz.z; sum.w += pz.w;
+                        }
+                    }
+                    v[r][0] = sum.x; v[r][1] = sum.y; v[r][2] = sum.z; v[r][3] = sum.w;
+                }
+                finish(t, v);
+                store_tile(t, y, v);
+            }
+        }
+        return;
     }
     }
-    }
+}
+
+size_t conv3x3_ksplit_counter_bytes() { return (size_t)kKsCounters * sizeof(float); }
+size_t conv3x3_ksplit_floats(int B, int Cout, int h, int w) {
+    return ((long)B * h * w <= 16384) ? (size_t)kKsCounters + (size_t)8 * B * Cout * h * w : 0;
+}
+
+// input-channel split of a launch whose every tile has its own workgroup: 1 = none
+static int ksplit_for(const Conv3x3Args& a, int ntiles, int ngroups, int vec, const dim3& grid) {
+    if (!a.ks_scratch || !vec || !aligned16(a.ks_scratch)) return 1;
+    const long total = (long)ntiles * ngroups * a.B;
+    const int nchunks = cdiv(a.Cin, KC);
+    // only for launches of at most 64 workgroups, split into at most 256: the device-scope fences of the hand-over (an L2
+    // write-back and invalidate per workgroup) made a 256-workgroup launch split three ways 2.8 x SLOWER (46 -> 129 us)
+    if (total > 64 || total > kKsCounters || nchunks < 8 || (long)grid.x != (long)ngroups * ntiles) return 1;
+    int S = nchunks / 4;
+    if (S > 8) S = 8;
+    while (S > 1 && total * S > 256) --S;
+    if (S < 2 || (size_t)kKsCounters + (size_t)S * a.B * a.Cout * a.h * a.w > a.ks_floats) return 1;
+    return S;
 }
 
 template <int NCO>
@@ -340,7 +442,11 @@ static void launch_rw(const Conv3x3Args& a, int ngroups, int vec, bool small, hi
     if (small && lrw == 0) {
         // few pixels (one frame at levels 2-3): 4-wave workgroups on 4x64 tiles, more of them
         const int txs = cdiv(a.w, 64), ntiles = txs * cdiv(a.h, 4);
-        conv3x3_kernel<NCO, 0, 1, 4><<<grid_for_tiles(ntiles), 256, 0, st>>>(a, ngroups, txs, ntiles, vec);
+        dim3 grid = grid_for_tiles(ntiles);
+        const int S = ksplit_for(a, ntiles, ngroups, vec, grid);
+        grid.z = (unsigned)S;
+        if (S > 1) conv3x3_kernel<NCO, 0, 1, 4, true><<<grid, 256, 0, st>>>(a, ngroups, txs, ntiles, vec);
+        else conv3x3_kernel<NCO, 0, 1, 4><<<grid, 256, 0, st>>>(a, ngroups, txs, ntiles, vec);
     } else if (NCO == 1 && lrw == 0 && a.h >= 16) {
         // one output tile: 16 waves of one row each (103 registers, four waves per SIMD cover each other's LDS and
         // barrier waits) beat 8 waves of two rows by 7 %; with NCO = 2 the same shape spills at the 128-register cap
@@ -354,8 +460,14 @@ static void launch_rw(const Conv3x3Args& a, int ngroups, int vec, bool small, hi
         conv3x3_kernel<NCO, 0, 1, 8><<<grid_for_tiles(ntiles), 512, 0, st>>>(a, ngroups, txs, ntiles, vec);
     } else {
         const int txs = cdiv(a.w, 64 >> lrw), ntiles = txs * cdiv(a.h, 4 << lrw);
-        const dim3 grid = grid_for_tiles(ntiles);
-        if (lrw == 0) conv3x3_kernel<NCO, 0, 1, 4><<<grid, 256, 0, st>>>(a, ngroups, txs, ntiles, vec);
+        dim3 grid = grid_for_tiles(ntiles);
+        const int S = ksplit_for(a, ntiles, ngroups, vec, grid);
+        grid.z = (unsigned)S;
+        if (S > 1) {
+            if (lrw == 0) conv3x3_kernel<NCO, 0, 1, 4, true><<<grid, 256, 0, st>>>(a, ngroups, txs, ntiles, vec);
+            else if (lrw == 1) conv3x3_kernel<NCO, 1, 1, 4, true><<<grid, 256, 0, st>>>(a, ngroups, txs, ntiles, vec);
+            else conv3x3_kernel<NCO, 2, 1, 4, true><<<grid, 256, 0, st>>>(a, ngroups, txs, ntiles, vec);
+        } else if (lrw == 0) conv3x3_kernel<NCO, 0, 1, 4><<<grid, 256, 0, st>>>(a, ngroups, txs, ntiles, vec);
         else if (lrw == 1) conv3x3_kernel<NCO, 1, 1, 4><<<grid, 256, 0, st>>>(a, ngroups, txs, ntiles, vec);
         else conv3x3_kernel<NCO, 2, 1, 4><<<grid, 256, 0, st>>>(a, ngroups, txs, ntiles, vec);
     }

@@ -143,6 +143,7 @@ struct Plan {
     size_t total = 0;
     size_t gscratch, guide[4], skip[3], tA, tB, tU, bufA, bufB, x1, trans, xs, cr;
     size_t gram_partial, wfold_attn, wfold_cr, wfold_attn3, wfold_cr3, flca_partial, ch;
+    size_t ks, ks_floats;       // scratch of the 3x3 convs' input-channel split (small frames only: ks_floats = 0 otherwise)
     int guide_planes;
 };
 
@@ -208,6 +209,12 @@ int make_plan(const rf_handle* h, int B, int H, int W, Plan& p) {
     p.wfold_cr3 = take(p, wc3);
     p.flca_partial = take(p, fp);
     p.ch = take(p, (size_t)B * (c.dim << 3));
+    p.ks_floats = 0;
+    for (int l = 0; l < 4; ++l) {
+        const size_t f = conv3x3_ksplit_floats(B, c.dim << l, H >> l, W >> l);
+        if (f > p.ks_floats) p.ks_floats = f;
+    }
+    p.ks = take(p, p.ks_floats);
     return RF_OK;
 }
 
@@ -364,6 +371,7 @@ int run_stage(rf_handle* h, int i, int lvl, const float* in, float* out, float* 
     Conv3x3Args co{};
     co.x = crb; co.x_bstride = (int64_t)C * Pn; co.wp = PK(h, pre + "Conv_out.weight"); co.bias = P(h, pre + "Conv_out.bias");
     co.out = out; co.out_bstride = (int64_t)C * Pn; co.B = B; co.Cin = C; co.Cout = C; co.h = hh; co.w = ww; co.act = 1;
+    if (p.ks_floats) { co.ks_scratch = ws + p.ks; co.ks_floats = p.ks_floats; }
     RF_TRY(launch_conv3x3(co, st));
     return RF_OK;
 }
@@ -592,6 +600,7 @@ int rf_forward_stage(rf_handle* h, int stage, const float* in, const float* pack
         RF_TRY(launch_guidance_base(packed, 0, h->cfg.clamp_io, ws + p.gscratch, B, H, W, st));
         RF_TRY(launch_guidance_level(ws + p.gscratch, ws + p.guide[lvl], B, H, W, H >> lvl, W >> lvl, st));
     }
+    if (p.ks_floats) RF_TRY(check_hip(hipMemsetAsync(ws + p.ks, 0, conv3x3_ksplit_counter_bytes(), st), "rf_forward_stage: memset"));
     return run_stage(h, stage, lvl, in, out, ws, p, B, H, W, st, st);
 }
 
@@ -622,6 +631,8 @@ int rf_forward(rf_handle* h, const float* in, float* out, void* workspace, size_
 
     const int levels = cfg.flca_levels > 0 ? cfg.flca_levels : 2;
     const hipStream_t side = branch_stream(h, st);
+    if (p.ks_floats)      // tickets of the 3x3 convs' input-channel split (the kernels leave them zero; the workspace is the caller's)
+        RF_TRY(check_hip(hipMemsetAsync(ws + p.ks, 0, conv3x3_ksplit_counter_bytes(), st), "rf_forward: memset"));
     if (cfg.variant == RF_VARIANT_FLCA) {
         // the guidance pyramid feeds the FLCA branches only: it runs on their stream, beside the embedding
         RF_TRY(fork_branch(h, st, side));
@@ -655,6 +666,7 @@ int rf_forward(rf_handle* h, const float* in, float* out, void* workspace, size_
         dn.x = skip[lvl]; dn.x_bstride = (int64_t)C * hh * ww; dn.wp = PK(h, "down" + std::to_string(i) + ".body.0.weight");
         dn.out = ws + p.tA; dn.out_bstride = (int64_t)2 * C * (hh / 2) * (ww / 2);
         dn.B = B; dn.Cin = C; dn.Cout = C / 2; dn.h = hh; dn.w = ww; dn.store = 1;
+        if (p.ks_floats) { dn.ks_scratch = ws + p.ks; dn.ks_floats = p.ks_floats; }
         RF_TRY(launch_conv3x3(dn, st));
     }
     RF_TRY(run_stage(h, 4, 3, ws + p.tA, ws + p.tB, ws, p, B, H, W, st, side));
