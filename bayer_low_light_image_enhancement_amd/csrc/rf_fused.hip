@@ -875,6 +875,7 @@ int fused_attn_plan(int h, int w, int* nslab, size_t* partial_floats, int B, int
                                                 // batch-invariant
     if (ntiles <= 256) ns = ntiles;             // frames up to 256 x 256 packed: one tile per workgroup (a workgroup's tiles are a
                                                 // chain of ~15 us each: 62 -> 25 us per launch for one 128 x 128 frame)
+                                                // (two tiles per workgroup at 512 x 512: -17 % for one frame, +11 % for a batch of 8)
     if (ns < 1) ns = 1;
     *nslab = ns;
     *partial_floats = (size_t)B * ns * (C / 16) * 16 * 66;
