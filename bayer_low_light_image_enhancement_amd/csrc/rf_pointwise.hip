@@ -506,6 +506,84 @@ __global__ void __launch_bounds__(kBlock) dwconv3x3_kernel(DwConvArgs a) {
     }
 }
 
+// The same strips with the two edge taps of every row taken from the NEIGHBOURING LANES instead of from memory.  In the kernel
+// above a row costs three load instructions -- the 16-byte segment and two dwords one pixel outside it -- and the dword loads
+// touch as many cache lines as the segment load: 3 x the L1 work of the data, and the kernel sat at 0.55 x HBM.  Here a wave
+// covers 62 consecutive strips of the x-fastest strip order with lanes 1 .. 62; lanes 0 and 63 load the strips before and after
+// them and only lend their edge pixels (3 % of the lanes do no arithmetic).  Strips at the ends of a row need no neighbour (zero
+// padding), so the order may run on across rows and planes.  w % 4 == 0.
+template <int ROWS>
+__global__ void __launch_bounds__(kBlock) dwconv3x3_halo_kernel(DwConvArgs a) {
+    const int w = a.w_, h = a.h;
+    const int wv = w >> 2;
+    const int hr = (h + ROWS - 1) / ROWS;
+    const long items = (long)a.B * a.C * hr * wv;
+    const int lane = threadIdx.x & 63;
+    const long nwave = (items + 61) / 62;
+    for (long wid = (blockIdx.x * (long)kBlock + threadIdx.x) >> 6; wid < nwave; wid += ((long)gridDim.x * kBlock) >> 6) {
+        const long itr = wid * 62 + lane - 1;                        // lanes 0 / 63: the strips before / after this wave's 62
+        const bool mine = lane >= 1 && lane <= 62 && itr < items;
+        const long it = itr < 0 ? 0 : (itr < items ? itr : items - 1);
+        const int xv = (int)(it % wv);
+        const int yr = (int)((it / wv) % hr);
+        const size_t pl = (size_t)(it / ((long)wv * hr));
+        const int c = (int)(pl % a.C);
+        const size_t b = pl / a.C;
+        const float* x = a.x + b * a.x_bstride + (size_t)c * h * w;
+        float* o = a.out + b * a.out_bstride + (size_t)c * h * w;
+        float* o2 = a.out2 ? a.out2 + b * a.out_bstride + (size_t)c * h * w : nullptr;
+        float k[9];
+#pragma unroll
+        for (int i = 0; i < 9; ++i) k[i] = a.w[c * 9 + i];
+        const float bias = a.bias ? a.bias[c] : 0.f;
+        const int x0 = xv * 4, y0 = yr * ROWS;
+        const bool has_l = x0 > 0, has_r = x0 + 4 < w;              // inside a row the neighbouring lane holds the neighbouring strip
+        float acc[ROWS][4];
+#pragma unroll
+        for (int r = 0; r < ROWS; ++r)
+#pragma unroll
+            for (int v = 0; v < 4; ++v) acc[r][v] = bias;
+#pragma unroll
+        for (int rr = 0; rr < ROWS + 2; ++rr) {
+            const int y = y0 + rr - 1;
+            const bool rok = y >= 0 && y < h;
+            const float4 t = *reinterpret_cast<const float4*>(x + (size_t)(rok ? y : 0) * w + x0);
+            const float lft = __shfl_up(t.w, 1), rgt = __shfl_down(t.x, 1);
+            float v[6];
+            v[0] = (rok && has_l) ? lft : 0.f;
+            v[1] = rok ? t.x : 0.f; v[2] = rok ? t.y : 0.f; v[3] = rok ? t.z : 0.f; v[4] = rok ? t.w : 0.f;
+            v[5] = (rok && has_r) ? rgt : 0.f;
+#pragma unroll
+            for (int r = 0; r < ROWS; ++r) {
+                const int ky = rr - r;
+                if (ky >= 0 && ky < 3) {
+#pragma unroll
+                    for (int p = 0; p < 4; ++p)
+                        acc[r][p] = fmaf(k[ky * 3 + 2], v[p + 2], fmaf(k[ky * 3 + 1], v[p + 1], fmaf(k[ky * 3], v[p], acc[r][p])));
+                }
+            }
+        }
+        if (!mine) continue;
+#pragma unroll
+        for (int r = 0; r < ROWS; ++r) {
+            const int y = y0 + r;
+            if (y < h) {
+                if (a.gelu) {
+#pragma unroll
+                    for (int p = 0; p < 4; ++p) acc[r][p] = gelu_fast(acc[r][p]);
+                }
+                *reinterpret_cast<float4*>(o + (size_t)y * w + x0) = make_float4(acc[r][0], acc[r][1], acc[r][2], acc[r][3]);
+                if (o2) {
+                    float gv[4];
+#pragma unroll
+                    for (int p = 0; p < 4; ++p) gv[p] = 0.5f * acc[r][p] * (1.0f + erff(acc[r][p] * 0.70710678118654752440f));
+                    *reinterpret_cast<float4*>(o2 + (size_t)y * w + x0) = make_float4(gv[0], gv[1], gv[2], gv[3]);
+                }
+            }
+        }
+    }
+}
+
 int launch_dwconv3x3(const DwConvArgs& a, hipStream_t st) {
     RF_CHECK_ARG(!a.out2 || (!a.gelu && aligned16(a.out2)), "dwconv3x3: out2 is the activated copy of a pre-activation out (gelu = 0), 16-byte aligned");
     const bool vec = (a.w_ & 3) == 0 && aligned16(a.x) && aligned16(a.out) && (a.x_bstride & 3) == 0 && (a.out_bstride & 3) == 0;
@@ -513,14 +591,14 @@ int launch_dwconv3x3(const DwConvArgs& a, hipStream_t st) {
     const bool tall = vec && a.h % 8 == 0;   // 8 output rows per thread: 10 row loads per 8 rows instead of 6 per 4
     const bool vec2 = !vec && (a.w_ & 1) == 0 && aligned16(a.x) && aligned16(a.out) && (a.x_bstride & 1) == 0 && (a.out_bstride & 1) == 0 &&
                       (((size_t)a.h * a.w_) & 1) == 0;
-    ProfScope prof(st, vec ? (tall ? "dwconv3x3_kernel<4, 8>" : "dwconv3x3_kernel<4, 4>") : vec2 ? "dwconv3x3_kernel<2, 8>" : "dwconv3x3_kernel<1, 4>",
+    ProfScope prof(st, vec ? (tall ? "dwconv3x3_halo_kernel<8>" : "dwconv3x3_halo_kernel<4>") : vec2 ? "dwconv3x3_kernel<2, 8>" : "dwconv3x3_kernel<1, 4>",
                    18.0 * el, 8.0 * el);
     if (tall) {
         const size_t items = (size_t)a.B * a.C * (a.h / 8) * (a.w_ / 4);
-        dwconv3x3_kernel<4, 8><<<grid_for(items), kBlock, 0, st>>>(a);
+        dwconv3x3_halo_kernel<8><<<grid_for((items + 61) / 62 * 64), kBlock, 0, st>>>(a);
     } else if (vec) {
         const size_t items = (size_t)a.B * a.C * cdiv(a.h, 4) * (a.w_ / 4);
-        dwconv3x3_kernel<4, 4><<<grid_for(items), kBlock, 0, st>>>(a);
+        dwconv3x3_halo_kernel<4><<<grid_for((items + 61) / 62 * 64), kBlock, 0, st>>>(a);
     } else if (vec2) {
         const size_t items = (size_t)a.B * a.C * cdiv(a.h, 8) * (a.w_ / 2);
         dwconv3x3_kernel<2, 8><<<grid_for(items), kBlock, 0, st>>>(a);
