@@ -114,6 +114,7 @@ class Trainer:
         self.loss_dev = torch.zeros(1, dtype=torch.float32, device=dev)
         # gradient all-reduce started range by range from inside rf_train_step (several ranks only)
         self.overlap = bool(overlap_allreduce)
+        self.overlap_always = overlap_allreduce == "always"      # also with a world of one (tests of the RCCL stream ordering)
         self.reducer = OverlappedReducer(self.grads, group, bucket_floats)
         self._reduced = False
         self._ready_cb = _lib.GRAD_READY_FN(lambda user, off, cnt, stream: self.reducer.ready(int(off), int(cnt)))   # kept alive with the Trainer
@@ -143,7 +144,7 @@ class Trainer:
             pred = torch.empty_like(gt) if want_pred else None
             stream = C.c_void_p(torch.cuda.current_stream(x.device).cuda_stream)
             import torch.distributed as dist
-            overlapped = self.overlap and dist.is_initialized() and dist.get_world_size(self.group) > 1
+            overlapped = self.overlap and dist.is_initialized() and (dist.get_world_size(self.group) > 1 or self.overlap_always)
             _lib.check(lib.rf_set_grad_ready(self.state.handle, self._ready_cb if overlapped else _lib.GRAD_READY_FN(), None), "rf_set_grad_ready")
             if overlapped:
                 self.reducer.begin()

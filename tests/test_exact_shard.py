@@ -81,3 +81,20 @@ def test_too_little_context_is_visible():
     comparison itself against passing vacuously)."""
     recs = _run_two_ranks("flca", 384, 64, 16, 8)
     assert max(r["err_vs_hip_whole"] for r in recs) > 1e-4, recs
+
+
+@pytest.mark.gpu
+def test_single_rank_on_rccl_takes_the_nccl_branch_of_the_callback():
+    """Two ranks cannot share the one GPU of the test box under RCCL, so the two-rank tests above run their collectives over
+    gloo.  One rank CAN initialise the ``nccl`` backend: every statistics all-reduce of the sharded forward (and the final
+    all-gather) then goes through RCCL on the launch stream -- with a world of one they are identities, which is exactly what
+    the result must show: the sharded call equals the whole-frame forward bit for bit, and the oracle within tolerance."""
+    import json
+    with tempfile.TemporaryDirectory() as d:
+        env = dict(os.environ, RF_SHARD_BACKEND="nccl", HSA_ENABLE_IPC_MODE_LEGACY="0")
+        p = subprocess.run([sys.executable, os.path.join(HERE, "shard_worker.py"), "0", "1", os.path.join(d, "rdv"), "128", "64", "16", "flca",
+                            str(tiling.HALO_ROWS)], env=env, capture_output=True, text=True, timeout=300)
+    assert p.returncode == 0, (p.stdout + p.stderr)[-3000:]
+    r = json.loads([ln for ln in p.stdout.splitlines() if ln.startswith("{")][-1])
+    assert r["err_vs_hip_whole"] == 0.0, r
+    assert r["err_vs_oracle"] <= 5e-5 * max(r["scale"], 1.0), r

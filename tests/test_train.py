@@ -299,3 +299,42 @@ def test_train_step_announces_every_gradient_once_and_in_order(device):
         _lib.check(lib.rf_grad_range(tr.state.handle, i, C.byref(off), C.byref(num)), "range")
         assert (off.value, num.value) == (o, c)
         assert torch.equal(snaps[i], ref[o:o + c]), (i, o, c)          # final at announcement time
+
+
+@pytest.mark.gpu
+def test_overlapped_reducer_on_rccl_with_one_rank(device, tmp_path):
+    """The overlapped gradient all-reduce on the ``nccl`` backend (RCCL): with a world of one the collectives are identities, so a
+    step with ``overlap_allreduce='always'`` -- every bucket handed to RCCL from inside rf_train_step, behind the kernels that
+    wrote it, beside the rest of the backward -- must leave exactly the gradients, the loss and the updated weights of a step
+    without any communication.  (Two ranks cannot share the test box's one GPU under RCCL; the two-rank tests run on gloo.)"""
+    import subprocess
+    import sys
+    code = r'''
+import sys, os, torch, torch.distributed as dist
+sys.path.insert(0, sys.argv[1]); sys.path.insert(0, sys.argv[1] + "/tests")
+import cases
+from bayer_low_light_image_enhancement_amd import RawFormer, synth
+from bayer_low_light_image_enhancement_amd.train import Trainer
+dist.init_process_group("nccl", init_method="file://" + sys.argv[2], rank=0, world_size=1)
+dev = torch.device("cuda:0")
+dim, seed, b, hm, wm = 16, 61, 2, 64, 128
+x = torch.from_numpy(synth.bayer_mosaic(seed, b, hm, wm)).to(dev)
+gt = torch.from_numpy(synth.smooth_rgb(seed, b, hm, wm)).to(dev)
+res = {}
+for tag, ov in (("plain", False), ("overlapped", "always")):
+    m = RawFormer(dim=dim)
+    m.load_state_dict({**m.state_dict(), **cases.model_state(dim, seed, "flca")}, strict=True)
+    m = m.to(dev).train()
+    tr = Trainer(m, lr=1e-3, weight_decay=1e-2, decoupled=True, overlap_allreduce=ov, bucket_floats=1 << 14)
+    loss = tr.step(x, gt)
+    torch.cuda.synchronize()
+    res[tag] = (float(loss), tr.grads.clone(), tr.flat.clone(), len(tr.reducer.buckets))
+assert res["overlapped"][3] >= 3, res["overlapped"][3]                 # several buckets went through RCCL
+assert res["plain"][0] == res["overlapped"][0]
+assert torch.equal(res["plain"][1], res["overlapped"][1]) and torch.equal(res["plain"][2], res["overlapped"][2])
+print("ok", res["overlapped"][3])
+dist.destroy_process_group()
+'''
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run([sys.executable, "-c", code, cases.REPO, str(tmp_path / "rdv")], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, (r.stdout + r.stderr)[-3000:]
