@@ -18,6 +18,14 @@
 //       dq = (rq dc rk) k - diag(rq^2 rowsum(dc c)) q;     dk = (rq dc rk)^T q - diag(rk^2 colsum(dc c)) k
 //     i.e. d[q;k] = M2 [q;k] with a per-image 2C x 2C matrix and dv = blockdiag(A^T) do: two 1x1 GEMMs with per-image weights.
 // Variants 'plain' (conv branch) and 'flca' (rf_train.hip: launch_flca_backward).
+//
+// Schedule-level choices (round 3): every packed / transposed / tap-flipped weight form of the step is written by three batched
+// launches before the forward (pack cache, build_pack_list); bias gradients are row sums inside gram2; the depthwise 3x3 of the
+// FFN writes its pre-activation and GELU(.) in one pass; the halves of a concatenated-input gradient are read in place through
+// strides; both residual adds of a block ride on the LayerNorm adjoints; inside a stage every backward tensor has its own
+// buffer so that the weight-gradient kernels run on a second stream beside the dX chain (fork before each, join at the end of
+// the stage); finished ranges of the flat gradient buffer are announced to the caller (rf_set_grad_ready) from its end towards
+// its start so that the gradient all-reduce overlaps the rest of the backward.
 #include <cstring>
 #include <map>
 #include <string>
