@@ -370,13 +370,15 @@ __global__ void __launch_bounds__(64 * NWV, (NWV >= 8 || NCO >= 3) ? 1 : 2) conv
             }
         }
         __shared__ unsigned ticket;
-        __threadfence();                               // the partial tile is visible device-wide before the ticket is taken
+        // release (every workgroup: its partial tile is written back before the ticket is taken) / acquire (the last workgroup
+        // only: it must not read stale lines).  A full __threadfence() on both sides made EVERY workgroup invalidate its L2.
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
         __syncthreads();
         if (tid == 0) ticket = atomicAdd(counter, 1u);
         __syncthreads();
         if (ticket != (unsigned)(ksplit - 1)) return;  // not the last split of this tile
         if (tid == 0) *counter = 0u;                   // ready for the next launch (stream order)
-        __threadfence();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
 #pragma unroll
         for (int rr = 0; rr < RPW; ++rr) {
             const int y = ey0 + (wave * RPW + rr) * RW + rowj;
@@ -417,8 +419,9 @@ static int ksplit_for(const Conv3x3Args& a, int ntiles, int ngroups, int vec, co
     if (!a.ks_scratch || !vec || !aligned16(a.ks_scratch)) return 1;
     const long total = (long)ntiles * ngroups * a.B;
     const int nchunks = cdiv(a.Cin, KC);
-    // only for launches of at most 64 workgroups, split into at most 256: the device-scope fences of the hand-over (an L2
-    // write-back and invalidate per workgroup) made a 256-workgroup launch split three ways 2.8 x SLOWER (46 -> 129 us)
+    // only for launches of at most 64 workgroups, split into at most 256: a 256-workgroup launch split three ways was 2.2-2.8 x
+    // SLOWER (46 -> 103 us with release / acquire fences, 129 us with a full fence on both sides): the hand-over costs every
+    // workgroup an L2 write-back
     if (total > 64 || total > kKsCounters || nchunks < 8 || (long)grid.x != (long)ngroups * ntiles) return 1;
     int S = nchunks / 4;
     if (S > 8) S = 8;
